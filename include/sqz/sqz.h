@@ -1,0 +1,195 @@
+/* include/sqz/sqz.h -- C ABI of libsqz_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of leok7v/sqz: the LZ77 longest-match scan +
+ * adaptive-Huffman emit (encode) and its inverse (decode).  C99, plain pointers
+ * and sizes; no HIP or torch types appear in any signature (streams and device
+ * pointers travel as void*).
+ *
+ * Three layers, all backed by the same HIP kernels (there is NO CPU fallback:
+ * every entry point reports ENODEV when no gfx950 device can be opened):
+ *
+ *  1. single-stream API with the reference's documented names
+ *     (sqz_init / sqz_write_header / sqz_compress / sqz_read_header /
+ *      sqz_decompress, `struct sqz`, `sqz_type`, `struct bitstream`):
+ *       - names + call shape: /root/reference/shl/README.md:31-62,
+ *         /root/reference/README.md:66-131 ("H1" in SURVEY.md section 0)
+ *       - behaviour (bit-exact): attic/map_experiment/squeeze.h ("H0"):
+ *         compress :319-409, decompress :502-551, header :255-265/:444-456
+ *  2. the H0 vtable spelling `squeeze` (squeeze.h:109-131) for callers of the
+ *     attic harness (attic/map_experiment/test.c:54-61,114-134)
+ *  3. batch API over independent blocks -- the data-parallel hot path:
+ *     host-buffer flavour and device-resident flavour (what bench.py times).
+ *
+ * Errors are the reference's sticky errno integers (squeeze.h:82,224-237;
+ * bitstream.h:15,38,74): 0, EINVAL, E2BIG, ENOMEM; plus ENODEV (no GPU).
+ */
+#ifndef SQZ_AMD_SQZ_H
+#define SQZ_AMD_SQZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SQZ_API __attribute__((visibility("default")))
+#else
+#define SQZ_API
+#endif
+
+enum {
+    sqz_min_win_bits = 10,  /* squeeze.h:19  squeeze_min_win_bits */
+    sqz_max_win_bits = 15,  /* squeeze.h:20  squeeze_max_win_bits */
+    sqz_min_len      = 3,   /* squeeze.h:13  squeeze_deflate_len_min */
+    sqz_max_len      = 257, /* squeeze.h:15  squeeze_deflate_len_max */
+    sqz_header_bits  = 72   /* squeeze.h:255-265: 64 (bytes) + 8 (win_bits) */
+};
+
+/* ------------------------------------------------------------------ */
+/* bit stream over caller memory.  Replaces `bitstream` of
+ * attic/map_experiment/bitstream.h:7-18 in its memory mode (:34-43, :70-80).
+ * The 8-byte callback mode (`stream/output/input`, :16-17) cannot cross to the
+ * device; callers that need it replay `data[0..bytes)` through their callback.
+ *
+ * writer: { .data = buf, .capacity = sizeof buf }          -> .bytes produced
+ * reader: { .data = buf, .bytes = n }  (H0, attic test.c:110)  or
+ *         { .data = buf, .capacity = n } (H1, shl/README.md:47-48)           */
+typedef struct bitstream {
+    uint8_t* data;
+    uint64_t capacity; /* data[capacity] */
+    uint64_t bytes;    /* bytes written (writer) / available (reader) */
+    uint64_t read;     /* bytes consumed by the reader */
+    uint64_t b64;      /* bit shifting buffer (bitstream.h:13) */
+    int32_t  bits;     /* bit count inside b64 (bitstream.h:14) */
+    int32_t  error;    /* sticky errno (bitstream.h:15) */
+} bitstream;
+
+/* codec state.  Caller-owned, single-use per stream like the reference's
+ * (squeeze.h:333-334 inserts the NYT leaves at the start of every call).
+ * The trees themselves live on the device for the duration of a call; the
+ * struct carries the sticky error and the counters of the last call.        */
+struct sqz {
+    int32_t  error;       /* sticky errno: README.md:126-131, squeeze.h:82 */
+    int32_t  device;      /* HIP device ordinal used by the last call, -1 = default */
+    uint64_t tokens;      /* LZ77 tokens of the last sqz_compress */
+    uint64_t reserved[5];
+};
+typedef struct sqz sqz_type; /* README.md:128 */
+
+/* shl/README.md:37-38  `static struct sqz s; sqz_init(&s);` */
+SQZ_API void sqz_init(struct sqz* s);
+
+/* shl/README.md:34 spelling (2 arguments).  The H1 source is absent from the
+ * reference snapshot, so its framing cannot be pinned: this writes the 64-bit
+ * length only, LSB first (the first field of squeeze.h:255-265).            */
+SQZ_API void sqz_write_header(struct bitstream* bs, uint64_t bytes);
+SQZ_API void sqz_read_header(struct bitstream* bs, uint64_t* bytes);
+
+/* squeeze.h:255-265 / :444-456 framing, pinned by tests/golden: 64 bits of
+ * length + 8 bits of win_bits (10..15, else bs->error = EINVAL), LSB first,
+ * no alignment before the payload.                                          */
+SQZ_API void sqz_write_header_h0(struct bitstream* bs, uint64_t bytes, uint8_t win_bits);
+SQZ_API void sqz_read_header_h0(struct bitstream* bs, uint64_t* bytes, uint8_t* win_bits);
+
+/* squeeze.h:319-409.  `window` = 1u << win_bits (2..32768 accepted, like the
+ * reference's uint16_t argument; max distance is window-1).  Continues the bit
+ * stream wherever sqz_write_header* left it and zero-pads to a 64-bit boundary
+ * (bitstream.h:112-114).  Result in s->error (mirrored to bs->error), output
+ * size in bs->bytes.  E2BIG when bs->capacity is too small (bitstream.h:38). */
+SQZ_API void sqz_compress(struct sqz* s, struct bitstream* bs,
+                          const uint8_t* data, size_t bytes, uint32_t window);
+
+/* squeeze.h:502-551.  Decodes exactly `bytes` bytes (taken from the header). */
+SQZ_API void sqz_decompress(struct sqz* s, struct bitstream* bs,
+                            uint8_t* data, size_t bytes);
+
+/* ------------------------------------------------------------------ */
+/* H0 vtable spelling: squeeze.h:109-131.  `map_bits` must be 0 (the map
+ * experiment is disabled in the reference's default configuration,
+ * attic/map_experiment/test.c:30-31) -- anything else is EINVAL / NULL.     */
+typedef struct sqz squeeze_type;
+typedef struct {
+    squeeze_type* (*alloc)(uint8_t map_bits);
+    int  (*init_with)(squeeze_type* s, void* memory, size_t size, uint8_t map_bits);
+    void (*write_header)(bitstream* bs, uint64_t bytes, uint8_t win_bits);
+    void (*compress)(squeeze_type* s, bitstream* bs,
+                     const uint8_t* data, size_t bytes, uint16_t window);
+    void (*read_header)(bitstream* bs, uint64_t* bytes, uint8_t* win_bits);
+    void (*decompress)(squeeze_type* s, bitstream* bs, uint8_t* data, size_t bytes);
+    void (*free)(squeeze_type* s);
+} squeeze_interface;
+SQZ_API extern squeeze_interface squeeze;
+
+/* ------------------------------------------------------------------ */
+/* Batch API: n independent blocks, each a self-contained stream with fresh
+ * trees (squeeze.h:333-336), payload only (no header), every output a multiple
+ * of 8 bytes.  Block b reads  in[in_off[b] .. in_off[b+1])  and writes at most
+ * out_off[b+1]-out_off[b] bytes at out + out_off[b]; the size goes to
+ * out_bytes[b], the errno to err[b].  Offsets arrays have n+1 entries.
+ * out_off[b] must be a multiple of 8.                                       */
+
+/* worst-case compressed size of one block of `bytes` bytes (multiple of 8) */
+SQZ_API uint64_t sqz_bound(uint64_t bytes);
+
+/* host buffers in, host buffers out (H2D + kernels + D2H inside) */
+SQZ_API int sqz_encode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                              uint32_t window,
+                              uint8_t* out, const uint64_t* out_off,
+                              uint64_t* out_bytes, int32_t* err);
+SQZ_API int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                              uint8_t* out, const uint64_t* out_off,
+                              int32_t* err);
+
+/* Device-resident flavour: every pointer is a DEVICE pointer on the current
+ * HIP device (hipMalloc / torch.cuda tensor storage), `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.
+ * `scratch` must hold sqz_hip_encode_scratch_bytes(n, total_in_bytes).      */
+SQZ_API uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes);
+SQZ_API int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
+                                  uint32_t window,
+                                  void* d_out, const uint64_t* d_out_off,
+                                  uint64_t* d_out_bytes, int32_t* d_err,
+                                  void* d_scratch, uint64_t scratch_bytes,
+                                  void* stream);
+SQZ_API int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
+                                  void* d_out, const uint64_t* d_out_off,
+                                  int32_t* d_err, void* stream);
+
+/* The two encode stages on their own (parity tests pin each independently,
+ * SURVEY.md section 8c; also what a caller with its own entropy stage binds):
+ *  stage 1  squeeze.h:338-358 + greedy step :377-394 -> token words
+ *           literal 0x000000bb ; match 0x80000000 | len<<16 | dist
+ *           block b's tokens start at d_tokens + in_off[b] (one slot per byte)
+ *  stage 2  squeeze.h:278-315 + huffman.h + bitstream.h -> payload bytes    */
+SQZ_API int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
+                                uint32_t window, uint32_t* d_tokens,
+                                uint32_t* d_token_count, void* stream);
+SQZ_API int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
+                                   const uint32_t* d_token_count, uint32_t n,
+                                   void* d_out, const uint64_t* d_out_off,
+                                   uint64_t* d_out_bytes, int32_t* d_err,
+                                   void* stream);
+
+/* Live timing of the last kernels enqueued through this library on the
+ * calling thread's context, measured with HIP events ON THE LAUNCH STREAM.
+ * Enabled with sqz_hip_set_timing(1); values in milliseconds.               */
+typedef struct sqz_hip_timing {
+    float lz77_ms;
+    float huffman_ms;
+    float decode_ms;
+    uint32_t lz77_launches, huffman_launches, decode_launches;
+} sqz_hip_timing;
+SQZ_API void sqz_hip_set_timing(int enabled);
+SQZ_API int  sqz_hip_get_timing(sqz_hip_timing* out, int reset);
+
+/* device / build information; returns 0 when a gfx950 device is usable */
+SQZ_API int sqz_hip_device_info(char* name, size_t name_cap, int* compute_units,
+                                uint64_t* lds_bytes_per_cu);
+SQZ_API const char* sqz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQZ_AMD_SQZ_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libsqz_amd.so -- exactly the entry points include/sqz/*.h declare.
+
+The product path has no CPU fallback: a missing library is a hard error.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsqz_amd.so")
+
+
+class Bitstream(C.Structure):
+    """struct bitstream of include/sqz/sqz.h (bitstream.h:7-18, memory mode)."""
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("capacity", C.c_uint64),
+                ("bytes", C.c_uint64), ("read", C.c_uint64), ("b64", C.c_uint64),
+                ("bits", C.c_int32), ("error", C.c_int32)]
+
+
+class Sqz(C.Structure):
+    """struct sqz / sqz_type of include/sqz/sqz.h."""
+    _fields_ = [("error", C.c_int32), ("device", C.c_int32), ("tokens", C.c_uint64),
+                ("reserved", C.c_uint64 * 5)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("lz77_ms", C.c_float), ("huffman_ms", C.c_float), ("decode_ms", C.c_float),
+                ("lz77_launches", C.c_uint32), ("huffman_launches", C.c_uint32),
+                ("decode_launches", C.c_uint32)]
+
+
+class SqueezeInterface(C.Structure):
+    """squeeze_interface vtable (squeeze.h:109-125)."""
+    _fields_ = [
+        ("alloc", C.CFUNCTYPE(C.POINTER(Sqz), C.c_uint8)),
+        ("init_with", C.CFUNCTYPE(C.c_int, C.POINTER(Sqz), C.c_void_p, C.c_size_t, C.c_uint8)),
+        ("write_header", C.CFUNCTYPE(None, C.POINTER(Bitstream), C.c_uint64, C.c_uint8)),
+        ("compress", C.CFUNCTYPE(None, C.POINTER(Sqz), C.POINTER(Bitstream), C.c_void_p,
+                                 C.c_size_t, C.c_uint16)),
+        ("read_header", C.CFUNCTYPE(None, C.POINTER(Bitstream), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint8))),
+        ("decompress", C.CFUNCTYPE(None, C.POINTER(Sqz), C.POINTER(Bitstream), C.c_void_p,
+                                   C.c_size_t)),
+        ("free", C.CFUNCTYPE(None, C.POINTER(Sqz))),
+    ]
+
+
+# name -> (restype, argtypes); kept in sync with include/sqz/sqz.h + sqz_workload.h
+_u8p, _u32p, _u64p, _i32p, _vp = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_void_p)
+PROTOTYPES = {
+    "sqz_version": (C.c_char_p, []),
+    "sqz_hip_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "sqz_bound": (C.c_uint64, [C.c_uint64]),
+    "sqz_init": (None, [C.POINTER(Sqz)]),
+    "sqz_write_header": (None, [C.POINTER(Bitstream), C.c_uint64]),
+    "sqz_read_header": (None, [C.POINTER(Bitstream), _u64p]),
+    "sqz_write_header_h0": (None, [C.POINTER(Bitstream), C.c_uint64, C.c_uint8]),
+    "sqz_read_header_h0": (None, [C.POINTER(Bitstream), _u64p, _u8p]),
+    "sqz_compress": (None, [C.POINTER(Sqz), C.POINTER(Bitstream), _vp, C.c_size_t, C.c_uint32]),
+    "sqz_decompress": (None, [C.POINTER(Sqz), C.POINTER(Bitstream), _vp, C.c_size_t]),
+    "sqz_encode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "sqz_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "sqz_hip_encode_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
+    "sqz_hip_encode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
+                                        _vp, C.c_uint64, _vp]),
+    "sqz_hip_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "sqz_hip_lz77_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "sqz_hip_huffman_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sqz_hip_set_timing": (None, [C.c_int]),
+    "sqz_hip_get_timing": (C.c_int, [C.POINTER(Timing), C.c_int]),
+    "sqz_hip_zipf_blocks": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "sqz_zipf_cdf_table": (C.POINTER(C.c_uint32), []),
+}
+DATA_SYMBOLS = ["squeeze"]
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises loudly when it is missing (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m sqz_amd.build` "
+                "(hipcc --offload-arch=gfx950). sqz_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def squeeze_vtable():
+    return SqueezeInterface.in_dll(lib(), "squeeze")

@@ -1,0 +1,527 @@
+// sqz_amd/csrc/abi.hip -- the C ABI of libsqz_amd.so (include/sqz/sqz.h).
+//
+// Host side of the drop-in boundary: argument checks
+// with the reference's errno conventions, H2D / D2H staging for the host
+// flavour, kernel launches for the device flavour.  There is no CPU code path
+// for the codec itself: without a gfx950 device every call reports ENODEV.
+#include "../../include/sqz/sqz.h"
+#include "sqz_kernels.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t kMaxStream = 1ull << 31;     // per-stream limit (32-bit freq/tokens)
+
+// ---------------------------------------------------------------- device ctx
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) { return 0; }
+        if (p != nullptr) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return ENOMEM; }
+            want = n;
+        }
+        cap = want;
+        return 0;
+    }
+};
+
+struct Ctx {
+    std::mutex mu;
+    int  state = 0;                 // 0 = unprobed, 1 = ok, -1 = no device
+    char name[256] = {0};
+    int  cus = 0;
+    uint64_t lds = 0;
+    // staging pool of the host-buffer flavour (grow-only, guarded by mu)
+    DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit;
+};
+
+Ctx& ctx() { static Ctx c; return c; }
+
+int probe_locked(Ctx& c) {
+    if (c.state != 0) { return c.state > 0 ? 0 : ENODEV; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { c.state = -1; return ENODEV; }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { c.state = -1; return ENODEV; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "libsqz_amd: device '%s' is not gfx950; kernels are built for "
+                        "MI355X only\n", prop.gcnArchName);
+        c.state = -1;
+        return ENODEV;
+    }
+    snprintf(c.name, sizeof(c.name), "%s (%s)", prop.name, prop.gcnArchName);
+    c.cus = prop.multiProcessorCount;
+    c.lds = (uint64_t)prop.maxSharedMemoryPerMultiProcessor;
+    c.state = 1;
+    return 0;
+}
+
+int hip_errno(hipError_t e) {
+    if (e == hipSuccess) { return 0; }
+    if (e == hipErrorOutOfMemory) { return ENOMEM; }
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) { return ENODEV; }
+    fprintf(stderr, "libsqz_amd: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return EIO;
+}
+
+#define HIP_TRY(expr) do { const int _e = hip_errno(expr); if (_e != 0) { return _e; } } while (0)
+
+// ---------------------------------------------------------------- timing
+struct TimedSpan { hipEvent_t a, b; int kind; };
+struct Timing {
+    std::mutex mu;
+    bool enabled = false;
+    std::vector<TimedSpan> spans;
+    sqz_hip_timing acc = {};
+};
+Timing& timing() { static Timing t; return t; }
+
+struct SpanGuard {
+    hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on = false;
+    SpanGuard(hipStream_t stream, int k) : s(stream), kind(k) {
+        Timing& t = timing();
+        std::lock_guard<std::mutex> g(t.mu);
+        on = t.enabled;
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~SpanGuard() {
+        if (!on) { return; }
+        (void)hipEventRecord(b, s);
+        Timing& t = timing();
+        std::lock_guard<std::mutex> g(t.mu);
+        t.spans.push_back({a, b, kind});
+    }
+};
+
+// ---------------------------------------------------------------- host bit I/O
+// bitstream.h:28-63 / :65-103, memory mode, used only for the stream headers.
+void host_put_bit(bitstream* bs, int bit) {
+    if (bs->error != 0) { return; }
+    bs->b64 = (bs->b64 << 1) | (uint64_t)(bit & 1);
+    if (++bs->bits == 64) {
+        if (bs->data == NULL || bs->capacity == 0) { bs->error = EINVAL; return; }
+        for (int k = 0; k < 8 && bs->error == 0; k++) {
+            if (bs->bytes == bs->capacity) { bs->error = E2BIG; }
+            else { bs->data[bs->bytes++] = (uint8_t)(bs->b64 >> (56 - 8 * k)); }
+        }
+        bs->bits = 0;
+        bs->b64 = 0;
+    }
+}
+
+void host_put_bits(bitstream* bs, uint64_t v, int n) {
+    for (int b = 0; b < n && bs->error == 0; b++) { host_put_bit(bs, (int)((v >> b) & 1)); }
+}
+
+uint64_t reader_limit(const bitstream* bs) { return bs->bytes != 0 ? bs->bytes : bs->capacity; }
+
+int host_get_bit(bitstream* bs) {
+    if (bs->error != 0) { return 0; }
+    if (bs->bits == 0) {
+        if (bs->data == NULL) { bs->error = EINVAL; return 0; }
+        const uint64_t limit = reader_limit(bs);
+        bs->b64 = 0;
+        for (int k = 0; k < 8 && bs->error == 0; k++) {
+            if (bs->read == limit) { bs->error = E2BIG; }
+            else { bs->b64 |= (uint64_t)bs->data[bs->read++] << (56 - 8 * k); }
+        }
+        bs->bits = 64;
+    }
+    const int bit = (int)(bs->b64 >> 63);
+    bs->b64 <<= 1;
+    bs->bits--;
+    return bit;
+}
+
+uint64_t host_get_bits(bitstream* bs, int n) {
+    uint64_t v = 0;
+    for (int b = 0; b < n && bs->error == 0; b++) { v |= (uint64_t)host_get_bit(bs) << b; }
+    return v;
+}
+
+bool window_ok(uint32_t w) { return w >= 2 && w <= 32768; }
+
+int check_offsets(const uint64_t* off, uint32_t n, bool need8) {
+    for (uint32_t b = 0; b < n; b++) {
+        if (off[b + 1] < off[b] || off[b + 1] - off[b] > kMaxStream) { return EINVAL; }
+        if (need8 && (off[b] & 7u) != 0) { return EINVAL; }
+    }
+    return 0;
+}
+
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// host-buffer encode of n blocks; prefix = pending header bits of block 0
+// (single-stream API only).  Caller holds ctx().mu.
+int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                       uint32_t window, uint8_t* out, const uint64_t* out_off,
+                       uint64_t* out_bytes, int32_t* err,
+                       uint64_t prefix_acc, int prefix_fill, uint64_t* tokens_total) {
+    const uint64_t in_base = in_off[0], out_base = out_off[0];
+    const uint64_t total_in = in_off[n] - in_base, total_out = out_off[n] - out_base;
+    std::vector<uint64_t> io(n + 1), oo(n + 1);
+    for (uint32_t b = 0; b <= n; b++) { io[b] = in_off[b] - in_base; oo[b] = out_off[b] - out_base; }
+
+    int e;
+    if ((e = c.in.reserve(total_in + 16)) || (e = c.out.reserve(total_out + 16)) ||
+        (e = c.in_off.reserve((n + 1) * 8)) || (e = c.out_off.reserve((n + 1) * 8)) ||
+        (e = c.tokens.reserve((total_in + 64) * 4)) || (e = c.tok_count.reserve((size_t)n * 4)) ||
+        (e = c.out_bytes.reserve((size_t)n * 8)) || (e = c.err.reserve((size_t)n * 4))) {
+        return e;
+    }
+    hipStream_t st = nullptr;
+    if (total_in > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in + in_base, total_in, hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    {
+        SpanGuard g(st, 0);
+        sqzk::launch_lz77_scan((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
+                              (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, st);
+    }
+    {
+        SpanGuard g(st, 1);
+        sqzk::launch_huffman_emit((const uint32_t*)c.tokens.p, (const uint64_t*)c.in_off.p,
+                                 (const uint32_t*)c.tok_count.p, (uint8_t*)c.out.p,
+                                 (const uint64_t*)c.out_off.p, (uint64_t*)c.out_bytes.p,
+                                 (int32_t*)c.err.p, n, prefix_acc, prefix_fill, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_bytes, c.out_bytes.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t b = 0; b < n; b++) {
+        if (out_bytes[b] > 0) {
+            HIP_TRY(hipMemcpyAsync(out + out_off[b], (const uint8_t*)c.out.p + oo[b], out_bytes[b],
+                                   hipMemcpyDeviceToHost, st));
+        }
+    }
+    if (tokens_total != nullptr) {
+        std::vector<uint32_t> tc(n);
+        HIP_TRY(hipMemcpyAsync(tc.data(), c.tok_count.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint64_t sum = 0;
+        for (uint32_t b = 0; b < n; b++) { sum += tc[b]; }
+        *tokens_total = sum;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                       uint8_t* out, const uint64_t* out_off, int32_t* err,
+                       uint64_t start_bit, uint64_t* end_bit) {
+    const uint64_t in_base = in_off[0], out_base = out_off[0];
+    const uint64_t total_in = in_off[n] - in_base, total_out = out_off[n] - out_base;
+    std::vector<uint64_t> io(n + 1), oo(n + 1);
+    for (uint32_t b = 0; b <= n; b++) { io[b] = in_off[b] - in_base; oo[b] = out_off[b] - out_base; }
+    int e;
+    if ((e = c.in.reserve(total_in + 16)) || (e = c.out.reserve(total_out + 16)) ||
+        (e = c.in_off.reserve((n + 1) * 8)) || (e = c.out_off.reserve((n + 1) * 8)) ||
+        (e = c.err.reserve((size_t)n * 4)) || (e = c.end_bit.reserve((size_t)n * 8))) {
+        return e;
+    }
+    hipStream_t st = nullptr;
+    if (total_in > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in + in_base, total_in, hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    {
+        SpanGuard g(st, 2);
+        sqzk::launch_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
+                           (const uint64_t*)c.out_off.p, (int32_t*)c.err.p,
+                           (uint64_t*)c.end_bit.p, n, start_bit, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (total_out > 0) {
+        HIP_TRY(hipMemcpyAsync(out + out_base, c.out.p, total_out, hipMemcpyDeviceToHost, st));
+    }
+    if (end_bit != nullptr) {
+        HIP_TRY(hipMemcpyAsync(end_bit, c.end_bit.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+} // namespace
+
+// =========================================================================
+extern "C" {
+
+const char* sqz_version(void) { return "sqz_amd 0.1 (gfx950; H0 semantics, H1 names)"; }
+
+int sqz_hip_device_info(char* name, size_t name_cap, int* compute_units,
+                        uint64_t* lds_bytes_per_cu) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    const int e = probe_locked(c);
+    if (e != 0) { return e; }
+    if (name != NULL && name_cap > 0) { snprintf(name, name_cap, "%s", c.name); }
+    if (compute_units != NULL) { *compute_units = c.cus; }
+    if (lds_bytes_per_cu != NULL) { *lds_bytes_per_cu = c.lds; }
+    return 0;
+}
+
+uint64_t sqz_bound(uint64_t bytes) { return (2 * bytes + 1024 + 7) & ~(uint64_t)7; }
+
+void sqz_init(struct sqz* s) {
+    if (s == NULL) { return; }
+    memset(s, 0, sizeof(*s));
+    s->device = -1;
+}
+
+void sqz_write_header(struct bitstream* bs, uint64_t bytes) { host_put_bits(bs, bytes, 64); }
+
+void sqz_read_header(struct bitstream* bs, uint64_t* bytes) {
+    const uint64_t b = host_get_bits(bs, 64);
+    if (bs->error == 0 && bytes != NULL) { *bytes = b; }
+}
+
+void sqz_write_header_h0(struct bitstream* bs, uint64_t bytes, uint8_t win_bits) {
+    if (win_bits < sqz_min_win_bits || win_bits > sqz_max_win_bits) {   // squeeze.h:257-258
+        bs->error = EINVAL;
+    } else {
+        host_put_bits(bs, bytes, 64);
+        host_put_bits(bs, win_bits, 8);
+    }
+}
+
+void sqz_read_header_h0(struct bitstream* bs, uint64_t* bytes, uint8_t* win_bits) {
+    const uint64_t b = host_get_bits(bs, 64);
+    const uint64_t w = host_get_bits(bs, 8);
+    if (bs->error == 0) {
+        if (w < sqz_min_win_bits || w > sqz_max_win_bits) {             // squeeze.h:449-450
+            bs->error = EINVAL;
+        } else {
+            if (bytes != NULL) { *bytes = b; }
+            if (win_bits != NULL) { *win_bits = (uint8_t)w; }
+        }
+    }
+}
+
+void sqz_compress(struct sqz* s, struct bitstream* bs,
+                  const uint8_t* data, size_t bytes, uint32_t window) {
+    if (s == NULL || bs == NULL) { return; }
+    if (s->error != 0) { return; }                       // sticky: squeeze.h:337
+    if (bs->error != 0) { s->error = bs->error; return; } // squeeze.h:226-227
+    if (!window_ok(window) || bs->data == NULL || bs->capacity == 0 ||
+        (bytes > 0 && data == NULL) || bytes > kMaxStream || bs->bytes > bs->capacity) {
+        s->error = EINVAL;
+        return;
+    }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int e = probe_locked(c);
+    if (e != 0) { s->error = e; return; }
+    const uint64_t in_off[2] = {0, (uint64_t)bytes};
+    const uint64_t room = bs->capacity - bs->bytes;
+    const uint64_t out_off[2] = {0, room};
+    uint64_t produced = 0;
+    int32_t err = 0;
+    // the device writes into a staging slab; it lands behind the header bytes
+    e = encode_host_locked(c, data, in_off, 1, window, bs->data + bs->bytes, out_off,
+                           &produced, &err, bs->b64, bs->bits, &s->tokens);
+    if (e != 0) { s->error = e; return; }
+    bs->bytes += produced;
+    bs->b64 = 0;
+    bs->bits = 0;
+    if (err == E2BIG) { bs->error = E2BIG; }
+    s->error = err;
+}
+
+void sqz_decompress(struct sqz* s, struct bitstream* bs, uint8_t* data, size_t bytes) {
+    if (s == NULL || bs == NULL) { return; }
+    if (s->error != 0) { return; }
+    if (bs->error != 0) { s->error = bs->error; return; }
+    const uint64_t limit = reader_limit(bs);
+    if (bs->data == NULL || (bytes > 0 && data == NULL) || bytes > kMaxStream ||
+        bs->read > limit || (uint64_t)bs->bits > bs->read * 8) {
+        s->error = EINVAL;
+        return;
+    }
+    if (bytes == 0) { return; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int e = probe_locked(c);
+    if (e != 0) { s->error = e; return; }
+    const uint64_t start_bit = bs->read * 8 - (uint64_t)bs->bits;
+    const uint64_t in_off[2] = {0, limit};
+    const uint64_t out_off[2] = {0, (uint64_t)bytes};
+    int32_t err = 0;
+    uint64_t end_bit = 0;
+    e = decode_host_locked(c, bs->data, in_off, 1, data, out_off, &err, start_bit, &end_bit);
+    if (e != 0) { s->error = e; return; }
+    // leave the reader where the reference's would be (bitstream.h:65-93)
+    const uint64_t words = (end_bit + 63) / 64;
+    bs->read = words * 8 <= limit ? words * 8 : limit;
+    bs->bits = (int32_t)(words * 64 - end_bit);
+    bs->b64 = 0;
+    if (bs->bits > 0 && words * 8 <= limit) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) { w |= (uint64_t)bs->data[(words - 1) * 8 + k] << (56 - 8 * k); }
+        bs->b64 = w << (64 - bs->bits);
+    }
+    if (err == E2BIG) { bs->error = E2BIG; }
+    s->error = err;
+}
+
+// ------------------------------------------------------------------ vtable
+static squeeze_type* vt_alloc(uint8_t map_bits) {
+    if (map_bits != 0) { return NULL; }
+    squeeze_type* s = (squeeze_type*)calloc(1, sizeof(squeeze_type));
+    if (s != NULL) { sqz_init(s); }
+    return s;
+}
+static int vt_init_with(squeeze_type* s, void* memory, size_t size, uint8_t map_bits) {
+    if (map_bits != 0 || memory == NULL || s != memory || size != sizeof(squeeze_type)) { return EINVAL; }
+    sqz_init(s);
+    return 0;
+}
+static void vt_compress(squeeze_type* s, bitstream* bs, const uint8_t* data, size_t bytes,
+                        uint16_t window) {
+    sqz_compress(s, bs, data, bytes, window);
+}
+static void vt_free(squeeze_type* s) { free(s); }
+
+squeeze_interface squeeze = {
+    vt_alloc, vt_init_with, sqz_write_header_h0, vt_compress,
+    sqz_read_header_h0, sqz_decompress, vt_free
+};
+
+// ------------------------------------------------------------------ batch, host
+int sqz_encode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n, uint32_t window,
+                      uint8_t* out, const uint64_t* out_off, uint64_t* out_bytes, int32_t* err) {
+    if (n == 0) { return 0; }
+    if (in_off == NULL || out_off == NULL || out == NULL || out_bytes == NULL || err == NULL ||
+        !window_ok(window)) { return EINVAL; }
+    if (check_offsets(in_off, n, false) != 0 || check_offsets(out_off, n, true) != 0) { return EINVAL; }
+    if (in == NULL && in_off[n] != in_off[0]) { return EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    const int e = probe_locked(c);
+    if (e != 0) { return e; }
+    return encode_host_locked(c, in, in_off, n, window, out, out_off, out_bytes, err, 0, 0, nullptr);
+}
+
+int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                      uint8_t* out, const uint64_t* out_off, int32_t* err) {
+    if (n == 0) { return 0; }
+    if (in == NULL || in_off == NULL || out_off == NULL || err == NULL) { return EINVAL; }
+    if (check_offsets(in_off, n, true) != 0 || check_offsets(out_off, n, false) != 0) { return EINVAL; }
+    if (out == NULL && out_off[n] != out_off[0]) { return EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    const int e = probe_locked(c);
+    if (e != 0) { return e; }
+    return decode_host_locked(c, in, in_off, n, out, out_off, err, 0, nullptr);
+}
+
+// ------------------------------------------------------------------ batch, device
+uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes) {
+    return align_up((uint64_t)n * 4, 256) + (total_in_bytes + 64) * 4;
+}
+
+static int device_ready(void) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return probe_locked(c);
+}
+
+int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
+                        uint32_t* d_tokens, uint32_t* d_token_count, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_in == NULL || d_in_off == NULL || d_tokens == NULL || d_token_count == NULL ||
+        !window_ok(window)) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    SpanGuard g((hipStream_t)stream, 0);
+    sqzk::launch_lz77_scan((const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
+                          (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
+                           const uint32_t* d_token_count, uint32_t n, void* d_out,
+                           const uint64_t* d_out_off, uint64_t* d_out_bytes, int32_t* d_err,
+                           void* stream) {
+    if (n == 0) { return 0; }
+    if (d_tokens == NULL || d_in_off == NULL || d_token_count == NULL || d_out == NULL ||
+        d_out_off == NULL || d_out_bytes == NULL || d_err == NULL) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    SpanGuard g((hipStream_t)stream, 1);
+    sqzk::launch_huffman_emit(d_tokens, d_in_off, d_token_count, (uint8_t*)d_out, d_out_off,
+                             d_out_bytes, d_err, n, 0, 0, (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
+                          void* d_out, const uint64_t* d_out_off, uint64_t* d_out_bytes,
+                          int32_t* d_err, void* d_scratch, uint64_t scratch_bytes, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_scratch == NULL || scratch_bytes < sqz_hip_encode_scratch_bytes(n, 0)) { return EINVAL; }
+    uint32_t* counts = (uint32_t*)d_scratch;
+    uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + align_up((uint64_t)n * 4, 256));
+    int e = sqz_hip_lz77_blocks(d_in, d_in_off, n, window, tokens, counts, stream);
+    if (e != 0) { return e; }
+    return sqz_hip_huffman_blocks(tokens, d_in_off, counts, n, d_out, d_out_off, d_out_bytes,
+                                  d_err, stream);
+}
+
+int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, void* d_out,
+                          const uint64_t* d_out_off, int32_t* d_err, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL || d_err == NULL) {
+        return EINVAL;
+    }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    SpanGuard g((hipStream_t)stream, 2);
+    sqzk::launch_decode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_err, nullptr,
+                       n, 0, (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ timing
+void sqz_hip_set_timing(int enabled) {
+    Timing& t = timing();
+    std::lock_guard<std::mutex> g(t.mu);
+    t.enabled = enabled != 0;
+}
+
+int sqz_hip_get_timing(sqz_hip_timing* out, int reset) {
+    Timing& t = timing();
+    std::lock_guard<std::mutex> g(t.mu);
+    for (TimedSpan& s : t.spans) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (s.kind == 0) { t.acc.lz77_ms += ms; t.acc.lz77_launches++; }
+            if (s.kind == 1) { t.acc.huffman_ms += ms; t.acc.huffman_launches++; }
+            if (s.kind == 2) { t.acc.decode_ms += ms; t.acc.decode_launches++; }
+        }
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    t.spans.clear();
+    if (out != NULL) { *out = t.acc; }
+    if (reset) { t.acc = sqz_hip_timing{}; }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,29 @@
+// sqz_amd/csrc/sqz_kernels.h -- host-visible launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sqzk {
+
+// stage 1: LZ77 brute-force longest-match scan + greedy parse
+// (attic/map_experiment/squeeze.h:338-358, :377-394).  Block b reads
+// in[in_off[b] .. in_off[b+1]) and writes its token words at
+// tokens + in_off[b]; the count goes to tok_count[b].
+void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                      uint32_t window, uint32_t* tokens, uint32_t* tok_count,
+                      hipStream_t stream);
+
+// stage 2: adaptive-Huffman emit (squeeze.h:278-315, huffman.h, bitstream.h)
+void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
+                         const uint32_t* tok_count, uint8_t* out,
+                         const uint64_t* out_off, uint64_t* out_bytes,
+                         int32_t* err, uint32_t n_blocks,
+                         uint64_t prefix_acc, int prefix_fill, hipStream_t stream);
+
+// decode (squeeze.h:502-551)
+void launch_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
+                   const uint64_t* out_off, int32_t* err, uint64_t* end_bit,
+                   uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
+
+} // namespace sqzk

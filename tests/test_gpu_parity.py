@@ -1,0 +1,310 @@
+"""GPU parity tests: every call goes through the C ABI of libsqz_amd.so and is
+compared bit for bit with the oracle (CPU restatement, pinned by tests/golden) and
+with the committed golden vectors generated from the reference itself.
+
+Nothing here reads /root/reference: the GPU box does not have it."""
+import ctypes as C
+import errno
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+G = O.golden()
+
+
+@pytest.fixture(scope="module")
+def sq():
+    import torch
+    assert torch.cuda.is_available()
+    import sqz_amd
+    info = sqz_amd.device_info()          # fails loudly if the HIP library is unusable
+    assert "gfx950" in info["name"]
+    return sqz_amd
+
+
+@pytest.fixture(scope="module")
+def batch(sq):
+    from sqz_amd import batch as b
+    return b
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("v", G["vectors"],
+                         ids=lambda v: f"{v['name']}-w{v['win_bits']}-h{int(v['header'])}")
+def test_small_vectors(sq, v):
+    data = bytes.fromhex(v["input_hex"])
+    if v["header"]:
+        out = sq.compress(data, win_bits=v["win_bits"], header=True)
+        assert out.hex() == v["out_hex"]
+        assert sq.decompress(out, header=True) == data
+    else:
+        out = sq.compress(data, win_bits=v["win_bits"], header=False)
+        assert out.hex() == v["out_hex"]
+        assert sq.decompress(out, header=False, nbytes=len(data)) == data
+
+
+@pytest.mark.parametrize("c", G["corpus"], ids=lambda c: f"{c['file']}-w{c['win_bits']}")
+def test_corpus_fingerprints(sq, c):
+    """BASELINE configs[1] and [4]: single stream, LDS-staged window, bit-exact."""
+    data = O.corpus(c["file"])
+    assert O.fnv(data) == c["in_fnv"]
+    out = sq.compress(data, win_bits=c["win_bits"], header=True)
+    assert len(out) == c["out_bytes"] and O.fnv(out) == c["out_fnv"]
+    gold = os.path.join(O.GOLD, f"{c['file']}.w{c['win_bits']}.sqz")
+    if os.path.exists(gold):
+        with open(gold, "rb") as fh:
+            assert out == fh.read()
+    assert sq.decompress(out, header=True) == data
+
+
+def test_zipf_fullsize_fingerprints(sq, batch):
+    """configs[2] check values of SURVEY.md section 8d: blocks 0 and 1 at 2^15."""
+    import torch
+    z = {x["block"]: x for x in G["zipf"] if x["in_bytes"] == 262144}
+    n, bb = 2, 262144
+    d_in = batch.zipf_blocks(n, bb)
+    off = batch.uniform_offsets(n, bb)
+    enc = batch.Encoder(n, n * bb, sq.bound(bb))
+    out, out_off, out_bytes, err = enc.encode(d_in, off, 1 << 15)
+    torch.cuda.synchronize()
+    assert err.tolist() == [0, 0]
+    h_in, h_out = d_in.cpu().numpy(), out.cpu().numpy()
+    for b in range(n):
+        assert O.fnv(h_in[b * bb:(b + 1) * bb].tobytes()) == z[b]["in_fnv"]
+        got = h_out[int(out_off[b]):int(out_off[b]) + int(out_bytes[b])].tobytes()
+        assert len(got) == z[b]["out_bytes"] and O.fnv(got) == z[b]["out_fnv"]
+
+
+# ---------------------------------------------------------------- vs oracle, live
+def _rand_cases(seed):
+    rng = random.Random(seed)
+    cases = [b"", b"a", b"ab", b"abc", b"aaa", b"abab" * 100, bytes(5000), bytes(range(256)) * 4,
+             b"x" * 257, b"x" * 258, b"x" * 259, b"x" * 260, b"xy" * 300, b"\x00\xff" * 129 + b"\x00"]
+    for _ in range(30):
+        n = rng.randint(0, 6000)
+        alpha = rng.choice([2, 3, 5, 16, 64, 256])
+        cases.append(bytes(rng.randrange(alpha) for _ in range(n)))
+    # repeated phrases at long distances (exercise the far end of the window)
+    phrase = bytes(rng.randrange(256) for _ in range(40))
+    cases.append(phrase + bytes(rng.randrange(256) for _ in range(1000)) + phrase +
+                 bytes(rng.randrange(256) for _ in range(1015 - 40)) + phrase * 2)
+    return cases
+
+
+def test_batch_ragged_vs_oracle(sq, batch):
+    """ragged + empty blocks in one launch; payload-only framing."""
+    cases = _rand_cases(1)
+    for window in (1 << 10, 1 << 12, 1 << 15):
+        outs, err = batch.encode_blocks_host(cases, window)
+        assert not err.any()
+        for data, got in zip(cases, outs):
+            assert got == O.encode(data, 15, header=False, window=window), (len(data), window)
+        back, derr = batch.decode_blocks_host(outs, [len(c) for c in cases])
+        assert not derr.any()
+        assert back == [bytes(c) for c in cases]
+
+
+@pytest.mark.parametrize("window", [2, 3, 4, 5, 8, 100, 1023, 1024, 4097, 32767, 32768])
+def test_window_sweep(sq, batch, window):
+    rng = random.Random(window)
+    data = bytes(rng.choice(b"abcde") for _ in range(3000)) + O.zipf_block(9, 3000) + bytes(600)
+    outs, err = batch.encode_blocks_host([data], window)
+    assert err[0] == 0
+    assert outs[0] == O.encode(data, 15, header=False, window=window)
+
+
+def test_tokens_vs_oracle(sq, batch):
+    """stage 1 alone (bst.c differential pattern: the GPU finder equals brute force
+    at every token start) + golden token dump."""
+    import torch
+    blocks = [O.corpus("laozi.txt"), O.zipf_block(3, 20000), bytes(3000) + b"abc" * 700,
+              O.corpus("confucius.txt")[:30000]]
+    sizes = [len(b) for b in blocks]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device="cuda")
+    d_in = torch.tensor(np.frombuffer(b"".join(blocks), np.uint8), device="cuda")
+    enc = batch.Encoder(len(blocks), sum(sizes), sq.bound(max(sizes)))
+    for window in (1 << 15, 1 << 11):
+        toks, counts = enc.tokens(d_in, off, window)
+        torch.cuda.synchronize()
+        toks = toks.cpu().numpy().view(np.uint32)
+        for b, data in enumerate(blocks):
+            want = O.tokens(data, window)
+            assert int(counts[b]) == len(want)
+            got = toks[int(off[b]):int(off[b]) + len(want)]
+            assert (got == want).all(), (b, window)
+    want = np.load(os.path.join(O.GOLD, "laozi_tokens_w15.npy"))
+    toks, counts = enc.tokens(d_in, off, 1 << 15)
+    assert (toks.cpu().numpy().view(np.uint32)[:len(want)] == want).all()
+
+
+def test_zipf_batch_vs_oracle(sq, batch):
+    import torch
+    n, bb, wb = 64, 16384, 12
+    d_in = batch.zipf_blocks(n, bb, first_block=0)
+    h_in = d_in.cpu().numpy()
+    for b in (0, 5, 63):
+        assert h_in[b * bb:(b + 1) * bb].tobytes() == O.zipf_block(b, bb)
+    off = batch.uniform_offsets(n, bb)
+    enc = batch.Encoder(n, n * bb, sq.bound(bb))
+    out, out_off, out_bytes, err = enc.encode(d_in, off, 1 << wb)
+    torch.cuda.synchronize()
+    assert not err.any()
+    h_out = out.cpu().numpy()
+    for b in range(n):
+        got = h_out[int(out_off[b]):int(out_off[b]) + int(out_bytes[b])].tobytes()
+        assert got == O.encode(h_in[b * bb:(b + 1) * bb].tobytes(), wb, header=False), b
+    for z in G["zipf"]:
+        if z["in_bytes"] == bb and z["win_bits"] == wb:
+            b = z["block"]
+            got = h_out[int(out_off[b]):int(out_off[b]) + int(out_bytes[b])].tobytes()
+            assert O.fnv(got) == z["out_fnv"]
+    # device-resident decode of the slabs
+    d_back = torch.empty_like(d_in)
+    # decode takes (n+1) offsets: compact the payloads first
+    sizes = out_bytes.cpu().numpy()
+    c_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    comp = np.concatenate([h_out[int(out_off[b]):int(out_off[b]) + int(sizes[b])] for b in range(n)])
+    derr = batch.decode_blocks(torch.tensor(comp, device="cuda"), torch.tensor(c_off, device="cuda"),
+                               n, d_back, off)
+    torch.cuda.synchronize()
+    assert not derr.any() and torch.equal(d_back, d_in)
+
+
+def test_full_size_roundtrip_properties(sq, batch):
+    """BASELINE.json configs[2] at FULL size (4096 x 256 KB, window 32 KB): too big
+    for the oracle, so size-independent properties: encode -> decode identity on
+    device, every size a multiple of 8, and the pinned blocks 0/1 fingerprints."""
+    import torch
+    n, bb = 4096, 262144
+    d_in = batch.zipf_blocks(n, bb)
+    off = batch.uniform_offsets(n, bb)
+    enc = batch.Encoder(n, n * bb, sq.bound(bb))
+    out, out_off, out_bytes, err = enc.encode(d_in, off, 1 << 15)
+    torch.cuda.synchronize()
+    assert int(err.abs().sum()) == 0
+    sizes = out_bytes.cpu().numpy()
+    assert (sizes % 8 == 0).all() and sizes.min() > 200000 and sizes.max() < 240000
+    z = {x["block"]: x for x in G["zipf"] if x["in_bytes"] == bb}
+    for b in (0, 1):
+        got = out[int(out_off[b]):int(out_off[b]) + int(sizes[b])].cpu().numpy().tobytes()
+        assert len(got) == z[b]["out_bytes"] and O.fnv(got) == z[b]["out_fnv"]
+    # decode straight from the slabs: block b's stream is [out_off[b], out_off[b] + size)
+    # -> use slab offsets; the decoder needs only the start (size bounds the reads)
+    d_back = torch.zeros_like(d_in)
+    derr = batch.decode_blocks(out, out_off, n, d_back, off)
+    torch.cuda.synchronize()
+    assert int(derr.abs().sum()) == 0
+    assert torch.equal(d_back, d_in)
+
+
+# ---------------------------------------------------------------- API shapes / errors
+def test_h1_call_shape(sq):
+    """shl/README.md:16-73 sample, as written there (2-argument header)."""
+    from sqz_amd import _native as N
+    L = N.lib()
+    text = b"Lorem ipsum dolor sit amet. " * 3
+    comp = (C.c_uint8 * 1024)()
+    w = N.Bitstream(data=C.cast(comp, C.POINTER(C.c_uint8)), capacity=1024)
+    L.sqz_write_header(C.byref(w), len(text))
+    s = N.Sqz()
+    L.sqz_init(C.byref(s))
+    L.sqz_compress(C.byref(s), C.byref(w), text, len(text), 1 << 11)
+    assert s.error == 0 and w.bytes % 8 == 0
+    # payload bits equal the pinned H0 stream's payload: strip 64 vs 72 header bits
+    r = N.Bitstream(data=C.cast(comp, C.POINTER(C.c_uint8)), capacity=w.bytes)
+    n = C.c_uint64(0)
+    L.sqz_read_header(C.byref(r), C.byref(n))
+    assert n.value == len(text)
+    back = (C.c_uint8 * 1024)()
+    d = N.Sqz()
+    L.sqz_init(C.byref(d))
+    L.sqz_decompress(C.byref(d), C.byref(r), back, n.value)
+    assert d.error == 0 and bytes(back[:n.value]) == text
+
+
+def test_h0_vtable(sq):
+    """attic/map_experiment/test.c:54-61,114-134 call sequence via `squeeze`."""
+    from sqz_amd import _native as N
+    vt = N.squeeze_vtable()
+    data = b"\x01\x02\x03\x04" * 1024                       # attic test.c:202-205
+    comp = (C.c_uint8 * 4096)()
+    bs = N.Bitstream(data=C.cast(comp, C.POINTER(C.c_uint8)), capacity=4096)
+    vt.write_header(C.byref(bs), len(data), 10)
+    s = vt.alloc(0)
+    assert bool(s)
+    vt.compress(s, C.byref(bs), data, len(data), 1 << 10)
+    assert s.contents.error == 0
+    gold = [v for v in G["vectors"] if v["name"] == "rle1234" and v["header"]][0]
+    assert bytes(comp[:bs.bytes]).hex() == gold["out_hex"]
+    vt.free(s)
+    rd = N.Bitstream(data=C.cast(comp, C.POINTER(C.c_uint8)), bytes=bs.bytes)
+    n, wb = C.c_uint64(0), C.c_uint8(0)
+    vt.read_header(C.byref(rd), C.byref(n), C.byref(wb))
+    assert (n.value, wb.value) == (len(data), 10)
+    s = vt.alloc(0)
+    out = (C.c_uint8 * len(data))()
+    vt.decompress(s, C.byref(rd), out, n.value)
+    assert s.contents.error == 0 and bytes(out) == data
+    vt.free(s)
+    assert not bool(vt.alloc(16))                           # map experiment: out of scope
+
+
+def test_errors(sq, batch):
+    data = O.zipf_block(3, 2000)
+    # E2BIG on a full sink, partial output identical to the reference's (bitstream.h:36-43)
+    for cap in (64, 61, 8, 1):
+        with pytest.raises(sq.SqzError) as ei:
+            sq.compress(data, win_bits=10, header=True, capacity=cap)
+        assert ei.value.errno == errno.E2BIG
+    from sqz_amd import _native as N
+    L = N.lib()
+    buf = (C.c_uint8 * 61)()
+    bs = N.Bitstream(data=C.cast(buf, C.POINTER(C.c_uint8)), capacity=61)
+    L.sqz_write_header_h0(C.byref(bs), len(data), 10)
+    s = N.Sqz(); L.sqz_init(C.byref(s))
+    L.sqz_compress(C.byref(s), C.byref(bs), data, len(data), 1 << 10)
+    e, part = O.encode_err(data, 10, True, 61)
+    assert s.error == e == errno.E2BIG and bs.error == errno.E2BIG
+    assert bs.bytes == len(part) == 61 and bytes(buf[:61]) == part
+    # bad arguments
+    with pytest.raises(sq.SqzError) as ei:
+        sq.compress(data, win_bits=10, header=False, window=1)
+    assert ei.value.errno == errno.EINVAL
+    with pytest.raises(sq.SqzError) as ei:
+        sq.compress(data, win_bits=16, header=True)
+    assert ei.value.errno == errno.EINVAL
+    # truncated stream: E2BIG (bitstream.h:74); same as the oracle
+    full = sq.compress(data, win_bits=10, header=True)
+    with pytest.raises(sq.SqzError) as ei:
+        sq.decompress(full[:-8], header=True)
+    assert ei.value.errno == errno.E2BIG == O.decode(full[:-8], header=True)[0]
+    # per-block errors in a batch: one block too small a slab, the others fine
+    outs, err = batch.encode_blocks_host([data, b"", data[:8]], 1 << 10, capacity=64)
+    assert err.tolist() == [errno.E2BIG, 0, 0]
+    assert outs[1] == b"" and outs[2] == O.encode(data[:8], 10, header=False)
+
+
+def test_corrupt_streams_do_not_fault(sq, batch):
+    """hardening: flipped bits give an error or different bytes, never a fault, and
+    agree with the (equally hardened) oracle."""
+    rng = random.Random(3)
+    data = O.corpus("laozi.txt")[:6000]
+    comp = bytearray(sq.compress(data, win_bits=12, header=False))
+    streams, want = [], []
+    for _ in range(24):
+        c = bytearray(comp)
+        for _ in range(rng.randint(1, 4)):
+            c[rng.randrange(len(c))] ^= 1 << rng.randrange(8)
+        streams.append(bytes(c))
+        want.append(O.decode(bytes(c), header=False, nbytes=len(data)))
+    back, err = batch.decode_blocks_host(streams, [len(data)] * len(streams))
+    for (e, out, _), got, ge in zip(want, back, err):
+        assert ge == e
+        if e == 0:
+            assert got == out
