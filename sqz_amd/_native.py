@@ -84,6 +84,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m sqz_amd.build` "
                 "(hipcc --offload-arch=gfx950). sqz_amd has no CPU fallback.")
+        # torch owns device memory and streams in this package, so the library
+        # must bind to the SAME HIP runtime instance: load torch's first (its
+        # libamdhip64 has the same SONAME the linker recorded for ours).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)

@@ -221,10 +221,7 @@ struct Tree {
     }
 
     __device__ __forceinline__ Links ld(int i) const {
-        // one 64-bit LDS read for the four link fields
-        union { uint64_t u; Links l; } x;
-        x.u = *reinterpret_cast<const uint64_t*>(&link[i]);
-        return x.l;
+        return link[i];    // 8-byte aligned aggregate: one ds_read_b64
     }
 
     // huffman.h:41-62
