@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one encode pass (LZ77 scan + adaptive-Huffman emit) of the hot path
+over one batch of synthetic input that is already resident in HBM:
+BASELINE.json configs[2] = 4096 x 256 KB Zipf(s=1) blocks, window 32 KB, one
+independent stream per block.  With N ranks every rank owns its own 4096-block
+batch (global block ids rank*4096 ...), no data-path collective: weak scaling.
+`value` = uncompressed MB (10^6 B) encoded per second by all ranks.  The decode
+pass over the produced streams is timed right after, with the same K and W, and
+reported in the same line (`decode_MBps`), together with
+  roofline      dominant kernel (lz77_scan_kernel) vs the HBM roof; HIP events on
+                the launch stream, measured live in this process
+  cpu_baseline  the reference itself (oracle/_ref, built in the build container and
+                shipped as a .so) or, if absent, the oracle restatement, timed
+                single-thread on a bounded sample of the same workload (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_sample_blocks, block_bytes, win_bits):
+    """single-thread CPU encode/decode MB/s on blocks [0, n_sample_blocks)."""
+    import ctypes as C
+    import oracle_lib as O       # checker only: TEST INFRASTRUCTURE
+    kind = "reference" if O.REF is not None else "port"
+    enc_s = dec_s = 0.0
+    total = 0
+    for b in range(n_sample_blocks):
+        data = O.zipf_block(b, block_bytes)
+        t0 = time.perf_counter()
+        comp = O.ref_compress(data, win_bits, False) if kind == "reference" \
+            else O.encode(data, win_bits, header=False)
+        enc_s += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if kind == "reference":
+            out = C.create_string_buffer(block_bytes)
+            n = C.c_uint64(block_bytes)
+            e = O.REF.sqz_ref_decompress(comp, len(comp), 0, out, block_bytes, C.byref(n), None)
+            back = out.raw
+        else:
+            e, back, _ = O.decode(comp, header=False, nbytes=block_bytes)
+        dec_s += time.perf_counter() - t0
+        assert e == 0 and back == data
+        total += block_bytes
+    return {"value": round(total / enc_s / 1e6, 5), "unit": "MB/s", "cores": 1, "kind": kind,
+            "decode_value": round(total / dec_s / 1e6, 3),
+            "sample": f"Zipf blocks 0..{n_sample_blocks - 1} of the same workload "
+                      f"({n_sample_blocks} x {block_bytes} B, window 2^{win_bits}), "
+                      f"encode {enc_s:.1f} s + decode {dec_s:.2f} s on one host core "
+                      f"of {os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU")
+    ap.add_argument("--block-bytes", type=int, default=262144)
+    ap.add_argument("--win-bits", type=int, default=15)
+    ap.add_argument("--cpu-blocks", type=int, default=2, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sqz_amd import batch, shard
+    import sqz_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, bb, wb = args.blocks, args.block_bytes, args.win_bits
+    info = sqz_amd.device_info()
+
+    # ---- synthetic input, generated straight into HBM ------------------------
+    d_in = batch.zipf_blocks(n, bb, first_block=rank * n, device=dev)
+    in_off = batch.uniform_offsets(n, bb, device=dev)
+    enc = batch.Encoder(n, n * bb, sqz_amd.bound(bb), device=dev)
+    d_back = torch.empty_like(d_in)
+    derr = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def encode_step():
+        return enc.encode(d_in, in_off, 1 << wb)
+
+    def decode_step(out, out_off):
+        batch.decode_blocks(out, out_off, n, d_back, in_off, derr)
+
+    # ---- encode: W warmup + K timed steps -------------------------------------
+    for _ in range(args.warmup):
+        encode_step()
+    barrier()
+    batch.set_timing(True)
+    batch.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, out_off, out_bytes, err = encode_step()
+    barrier()
+    enc_s = time.perf_counter() - t0
+    tim = batch.get_timing(reset=True)
+    batch.set_timing(False)
+    assert int(err.abs().sum()) == 0, "encode reported errors"
+    comp_bytes = int(out_bytes.sum().item())
+
+    # ---- decode: same K / W ----------------------------------------------------
+    for _ in range(args.warmup):
+        decode_step(out, out_off)
+    barrier()
+    batch.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        decode_step(out, out_off)
+    barrier()
+    dec_s = time.perf_counter() - t0
+    dtim = batch.get_timing(reset=True)
+    batch.set_timing(False)
+    assert int(derr.abs().sum()) == 0, "decode reported errors"
+    if not args.no_verify:
+        assert torch.equal(d_back, d_in), "round trip differs"
+
+    if world > 1:
+        enc_s = shard.max_over_ranks(enc_s, dev)
+        dec_s = shard.max_over_ranks(dec_s, dev)
+        comp_total = shard.sum_over_ranks(float(comp_bytes), dev)
+    else:
+        comp_total = float(comp_bytes)
+
+    if rank == 0:
+        in_total = float(world) * n * bb
+        ms_per_step = enc_s / args.steps * 1e3
+        lz_ms = tim["lz77_ms"] / max(tim["lz77_launches"], 1)
+        hf_ms = tim["huffman_ms"] / max(tim["huffman_launches"], 1)
+        dk_ms = dtim["decode_ms"] / max(dtim["decode_launches"], 1)
+        algo_bytes = n * bb + comp_bytes          # encode = n + c per block
+        achieved = algo_bytes / (lz_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as fh:
+                traffic = json.load(fh).get("lz77_scan_kernel_hbm_bytes_per_launch")
+        line = {
+            "metric": "encode MB/s + decode MB/s, 32KB window, batched blocks, 1/2/4/8 MI355X",
+            "value": round(in_total / enc_s * args.steps / 1e6, 3),
+            "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{n} x {bb} B Zipf(s=1) byte blocks per GPU, window 2^{wb}, "
+                                   "one independent stream per block (BASELINE.json configs[2])",
+                       "blocks_per_gpu": n, "block_bytes": bb, "win_bits": wb,
+                       "parallelism": f"blocks sharded over {world} rank(s), no data-path collective",
+                       "device": info["name"]},
+            "decode_MBps": round(in_total / dec_s * args.steps / 1e6, 3),
+            "decode_ms_per_step": round(dec_s / args.steps * 1e3, 3),
+            "compressed_ratio": round(comp_total / in_total, 5),
+            "kernels_ms": {"lz77_scan": round(lz_ms, 3), "huffman_emit": round(hf_ms, 3),
+                           "decode": round(dk_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": "lz77_scan_kernel",
+                         "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 7), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and args.cpu_blocks > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_blocks, bb, wb)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Multi-GPU: independent blocks shard across ranks.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo"
+in the CPU tests).  Blocks are self-contained streams, so the data path needs no
+collective: rank r owns the contiguous block range block_range(n, r, world).
+The optional scatter / gather pair moves a root-resident batch out to the ranks and
+the compressed slabs back (point-to-point per peer link, no ring).
+
+The codec is passed in as a callable, this module never touches kernels itself."""
+import torch
+import torch.distributed as dist
+
+
+def block_range(n_blocks: int, rank: int, world: int):
+    """[lo, hi) of the blocks rank `rank` owns; contiguous, sizes differ by <= 1."""
+    return (n_blocks * rank) // world, (n_blocks * (rank + 1)) // world
+
+
+def scatter_blocks(root_blocks, n_blocks: int, block_bytes: int, device, group=None, src=0):
+    """root holds uint8[n_blocks*block_bytes]; every rank gets its own range.
+
+    Ranges are padded to the largest range so one `scatter` (ncclScatter shape:
+    equal slabs, rccl.h:767) serves all ranks."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    widest = max(block_range(n_blocks, r, world)[1] - block_range(n_blocks, r, world)[0]
+                 for r in range(world))
+    mine = torch.empty(widest * block_bytes, dtype=torch.uint8, device=device)
+    chunks = None
+    if rank == src:
+        chunks = []
+        for r in range(world):
+            lo, hi = block_range(n_blocks, r, world)
+            c = torch.zeros(widest * block_bytes, dtype=torch.uint8, device=device)
+            c[:(hi - lo) * block_bytes] = root_blocks[lo * block_bytes:hi * block_bytes]
+            chunks.append(c)
+    dist.scatter(mine, chunks, src=src, group=group)
+    lo, hi = block_range(n_blocks, rank, world)
+    return mine[:(hi - lo) * block_bytes], (lo, hi)
+
+
+def gather_slabs(local_slabs, local_sizes, n_blocks: int, slab_bytes: int, device, group=None, dst=0):
+    """Fixed-stride compressed slabs + their sizes back to `dst` in block order.
+
+    Returns (slabs uint8[n_blocks*slab_bytes], sizes int64[n_blocks]) on dst, (None, None)
+    elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    widest = max(block_range(n_blocks, r, world)[1] - block_range(n_blocks, r, world)[0]
+                 for r in range(world))
+    pad_slabs = torch.zeros(widest * slab_bytes, dtype=torch.uint8, device=device)
+    pad_slabs[:local_slabs.numel()] = local_slabs
+    pad_sizes = torch.zeros(widest, dtype=torch.int64, device=device)
+    pad_sizes[:local_sizes.numel()] = local_sizes
+    slabs_list = sizes_list = None
+    if rank == dst:
+        slabs_list = [torch.empty_like(pad_slabs) for _ in range(world)]
+        sizes_list = [torch.empty_like(pad_sizes) for _ in range(world)]
+    dist.gather(pad_slabs, slabs_list, dst=dst, group=group)
+    dist.gather(pad_sizes, sizes_list, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    slabs, sizes = [], []
+    for r in range(world):
+        lo, hi = block_range(n_blocks, r, world)
+        slabs.append(slabs_list[r][:(hi - lo) * slab_bytes])
+        sizes.append(sizes_list[r][:hi - lo])
+    return torch.cat(slabs), torch.cat(sizes)
+
+
+def max_over_ranks(value: float, device, group=None) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device, group=None) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())
