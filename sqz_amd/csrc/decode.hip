@@ -1,14 +1,16 @@
 // sqz_amd/csrc/decode.hip -- decoder (gfx950).
 //
-// One wavefront per stream:
+// One wavefront per stream, running uniformly:
 //   squeeze.h:502-551 squeeze_decompress   token loop
 //   squeeze.h:429-442 squeeze_read_huffman root->leaf walk, then frequency bump
 //   squeeze.h:458-474 squeeze_read_length
 //   squeeze.h:476-500 squeeze_read_pos
 //   squeeze.h:537-539 byte-serial overlapped copy (RLE when dist < len)
-// Lane 0 walks the adaptive trees (LDS resident) and reads bits; a back
-// reference is broadcast to the wave and copied by all 64 lanes with the
-// overlap rule  out[i+k] = out[i-dist + (k mod dist)].
+// The root->leaf walk hands level d of the path to lane d, so the frequency
+// update right after it is the parallel fast path of sqz_device.h (the walk has
+// already produced the chain the update needs).  Literals are byte stores by
+// lane 0; a back reference is copied by all 64 lanes with the overlap rule
+// out[i+k] = out[i-dist + (k mod dist)].
 //
 // Hardening (the reference only asserts): a missing
 // child, a raw symbol that is out of range or already in the tree, a distance
@@ -23,19 +25,47 @@ struct DecodeLds {
     EntropyLds entropy;
 };
 
+// squeeze.h:429-442; returns the leaf or -1 with err set
 template <class T>
-__device__ __forceinline__ int read_symbol(BitSource& r, T& t, int& err) {
-    int i = T::kRoot;
+__device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& err) {
+    int node = T::kRoot, d = 0;
+    int mine = (lane == 0) ? node : (int)kNil;
     for (;;) {
         const int bit = r.bit();
         if (r.error != 0) { err = r.error; return -1; }
-        const Links n = t.ld(i);
-        i = bit ? n.hi : n.lo;
-        if (i == kNil) { err = kEINVAL; return -1; }
-        if (i < (int)T::kRoot) { break; }                 // leaf ids < LEAVES
+        const int child = __builtin_amdgcn_readfirstlane(
+            (int)(bit ? t.link[node].hi : t.link[node].lo));
+        if (child == kNil) { err = kEINVAL; return -1; }
+        d++;
+        mine = (lane == d) ? child : mine;
+        node = child;
+        if (child < (int)T::kRoot) { break; }            // leaf ids < LEAVES
+        if (d >= kMaxFastDepth) { break; }               // finish serially below
     }
-    t.bump(i);
-    return i;
+    if (node >= (int)T::kRoot) {                         // deeper than the wave is wide
+        for (;;) {
+            const int bit = r.bit();
+            if (r.error != 0) { err = r.error; return -1; }
+            const int child = __builtin_amdgcn_readfirstlane(
+                (int)(bit ? t.link[node].hi : t.link[node].lo));
+            if (child == kNil) { err = kEINVAL; return -1; }
+            d++;
+            node = child;
+            if (child < (int)T::kRoot) { break; }
+            if (d >= 2 * kStack) { err = kEINVAL; return -1; }
+        }
+    }
+    // lane d' holds depth d' (0 = root, d = leaf)
+    Chain c;
+    c.mine = mine;
+    c.par = lane_below(mine);                            // lane d-1 holds the parent
+    c.gpar = lane_below(c.par);
+    c.levels = d;
+    c.holds = lane <= d;
+    c.active = lane >= 1 && lane <= d;
+    c.has_g = lane >= 2 && lane <= d;
+    t.bump_wave(node, c, lane);
+    return node;
 }
 
 __global__ __launch_bounds__(kWave)
@@ -66,67 +96,54 @@ void decode_kernel(const uint8_t* __restrict__ in,
     r.limit = in_off[b + 1] - in_off[b];
     r.error = 0;
     int err = 0;
-
-    if (lane == 0) {
-        r.seek(start_bit);
-        if (r.error != 0) { err = r.error; }
-        if (!lit.insert(kLitNyt)) { err = kEINVAL; }      // squeeze.h:505-506
-        if (!pos.insert(kPosNyt)) { err = kEINVAL; }
-    }
+    r.seek(start_bit);
+    if (r.error != 0) { err = r.error; }
+    if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
+    if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
     uint64_t i = 0;
-    for (;;) {
-        // ---- lane 0: decode literals until a back reference or the end ----
-        int len = 0, dist = 0;
-        if (lane == 0) {
-            while (i < bytes && err == 0) {
-                int s = read_symbol(r, lit, err);
-                if (err != 0) { break; }
-                if (s == kLitNyt) {                        // squeeze.h:512-520
-                    s = (int)r.get_lsb(9);
-                    if (r.error != 0) { err = r.error; break; }
-                    if (s == 256 || s >= kLitNyt || lit.link[s].up != kNil) {
-                        err = kEINVAL; break;
-                    }
-                    if (!lit.insert(s)) { err = kE2BIG; break; }
-                }
-                if (s <= 0xFF) { dst[i++] = (uint8_t)s; continue; }
-                int base, xb;                              // squeeze.h:458-474
-                len_base_of(s - kSymLen0, base, xb);
-                len = base;
-                if (xb != 0) {
-                    len += (int)r.get_lsb(xb);
-                    if (r.error != 0) { err = r.error; break; }
-                }
-                if (len < kLenMin || len > kLenMax) { err = kEINVAL; break; }
-                int pk = read_symbol(r, pos, err);         // squeeze.h:476-500
-                if (err != 0) { break; }
-                if (pk == kPosNyt) {
-                    pk = (int)r.get_lsb(5);
-                    if (r.error != 0) { err = r.error; break; }
-                    if (pk >= kPosNyt || pos.link[pk].up != kNil) { err = kEINVAL; break; }
-                    if (!pos.insert(pk)) { err = kE2BIG; break; }
-                }
-                pos_base_of(pk, base, xb);
-                dist = base;
-                if (xb != 0) {
-                    dist += (int)r.get_lsb(xb);
-                    if (r.error != 0) { err = r.error; break; }
-                }
-                if ((uint64_t)dist > i || (uint64_t)len > bytes - i) {
-                    err = kEINVAL; break;
-                }
-                if (lit.fault | pos.fault) { err = kE2BIG; }
-                break;                                     // hand the copy to the wave
-            }
-            if (err != 0) { len = 0; }
+    while (i < bytes && err == 0) {
+        int s = read_symbol(r, lit, lane, err);
+        if (err != 0) { break; }
+        if (s == kLitNyt) {                                            // squeeze.h:512-520
+            s = (int)r.get_lsb(9);
+            if (r.error != 0) { err = r.error; break; }
+            if (s == 256 || s >= kLitNyt) { err = kEINVAL; break; }
+            const int up = __builtin_amdgcn_readfirstlane((int)lit.link[s].up);
+            if (up != kNil) { err = kEINVAL; break; }
+            if (!lit.insert_wave(s, lane)) { err = kE2BIG; break; }
         }
-        // ---- whole wave: overlapped copy ----
-        len = __shfl(len, 0);
-        if (len == 0) { break; }                           // end of stream or error
-        dist = __shfl(dist, 0);
-        i = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(i >> 32), 0) << 32) |
-            (uint64_t)(uint32_t)__shfl((int)(uint32_t)i, 0);
+        if (s <= 0xFF) {
+            if (lane == 0) { dst[i] = (uint8_t)s; }
+            i++;
+            continue;
+        }
+        int base, xb;                                                  // squeeze.h:458-474
+        len_base_of(s - kSymLen0, base, xb);
+        int len = base;
+        if (xb != 0) {
+            len += (int)r.get_lsb(xb);
+            if (r.error != 0) { err = r.error; break; }
+        }
+        if (len < kLenMin || len > kLenMax) { err = kEINVAL; break; }
+        int pk = read_symbol(r, pos, lane, err);                       // squeeze.h:476-500
+        if (err != 0) { break; }
+        if (pk == kPosNyt) {
+            pk = (int)r.get_lsb(5);
+            if (r.error != 0) { err = r.error; break; }
+            if (pk >= kPosNyt) { err = kEINVAL; break; }
+            const int up = __builtin_amdgcn_readfirstlane((int)pos.link[pk].up);
+            if (up != kNil) { err = kEINVAL; break; }
+            if (!pos.insert_wave(pk, lane)) { err = kE2BIG; break; }
+        }
+        pos_base_of(pk, base, xb);
+        int dist = base;
+        if (xb != 0) {
+            dist += (int)r.get_lsb(xb);
+            if (r.error != 0) { err = r.error; break; }
+        }
+        if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; break; }
+        if (lit.fault | pos.fault) { err = kE2BIG; break; }
         // the source bytes were written by this wave: drain the stores, then
         // read them back from L2 (sc1), never from a possibly stale L1 line
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

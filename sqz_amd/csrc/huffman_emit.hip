@@ -8,8 +8,11 @@
 //   squeeze.h:239-246 squeeze_write_huffman    (code from the tree BEFORE the
 //                                               frequency update)
 //   squeeze.h:248-253 squeeze_flush
-// Tokens are fetched 256 at a time by all 64 lanes (16-byte coalesced loads)
-// into an LDS staging strip; the serial adaptive-Huffman chain runs on lane 0.
+// The wave runs uniformly: tokens are staged 256 at a time into LDS by all
+// lanes; per symbol lane k takes level k of the leaf->root chain, so the
+// Huffman code is one __ballot ("am I the hi child?") and the frequency update
+// is the parallel fast path of sqz_device.h (slow path on lane 0 when the tree
+// restructures).  The bit sink state is wave-uniform; lane 0 stores the words.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
@@ -22,25 +25,43 @@ struct EmitLds {
     uint32_t   strip[kTokStrip];
 };
 
-__device__ __forceinline__ void emit_symbol(BitSink& w, LitTree& t, int s) {
-    const Links n = t.ld(s);
-    w.put_msb(t.code[s], n.bits);
-    t.bump(s);
+// huffman code of attached leaf s, read off its chain: lane k contributes the
+// branch taken at level k; ballot bit k is then bit k of the stream-order code
+template <class T>
+__device__ __forceinline__ void emit_attached(BitSink& w, T& t, int s, const Chain& c, int lane) {
+    if (c.levels < kMaxFastDepth) {
+        bool is_hi = false;
+        if (c.active) { is_hi = (t.link[c.par].hi == c.mine); }
+        const uint64_t code = __ballot(is_hi);
+        w.put_msb(code, c.levels);
+    } else {                                   // deeper than the wave is wide: serial
+        uint64_t code = 0;
+        int n = 0, a = s;
+        for (;;) {
+            const int up = __builtin_amdgcn_readfirstlane((int)t.link[a].up);
+            if (up == kNil || n >= 63) { break; }
+            const int hi = __builtin_amdgcn_readfirstlane((int)t.link[up].hi);
+            code |= (uint64_t)(hi == a ? 1 : 0) << n;
+            a = up;
+            n++;
+        }
+        w.put_msb(code, n);
+    }
+    t.bump_wave(s, c, lane);                   // squeeze.h:245: after the code is out
 }
 
-__device__ __forceinline__ void emit_symbol(BitSink& w, PosTree& t, int s) {
-    const Links n = t.ld(s);
-    w.put_msb(t.code[s], n.bits);
-    t.bump(s);
-}
-
-__device__ __forceinline__ void emit_lit(BitSink& w, LitTree& lit, int s, int& err) {
-    if (lit.link[s].bits == 0) {                         // squeeze.h:280
-        emit_symbol(w, lit, kLitNyt);
-        w.put_lsb((uint32_t)s, 9);
-        if (!lit.insert(s)) { err = kE2BIG; }
+// squeeze.h:278-288 / :300-315: symbol through tree t with NYT escape
+template <class T>
+__device__ __forceinline__ void emit_coded(BitSink& w, T& t, int s, int nyt, int raw_bits,
+                                           int lane, int& err) {
+    const Chain c = t.chain_up(s, lane);
+    if (c.levels == 0) {                       // unseen (node[s].bits == 0)
+        const Chain cn = t.chain_up(nyt, lane);
+        emit_attached(w, t, nyt, cn, lane);
+        w.put_lsb((uint32_t)s, raw_bits);
+        if (!t.insert_wave(s, lane)) { err = kE2BIG; }
     } else {
-        emit_symbol(w, lit, s);
+        emit_attached(w, t, s, c, lane);
     }
 }
 
@@ -75,49 +96,39 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     w.acc = prefix_acc;
     w.fill = prefix_fill;
     w.error = 0;
+    w.writer = (lane == 0);
     int err = 0;
 
-    if (lane == 0) {                                      // squeeze.h:333-334
-        if (!lit.insert(kLitNyt)) { err = kEINVAL; }
-        if (!pos.insert(kPosNyt)) { err = kEINVAL; }
-    }
+    if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
+    if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
-    for (uint32_t base = 0; base < count; base += kTokStrip) {
-        // all lanes: stage the next strip of tokens
+    for (uint32_t base = 0; base < count && err == 0; base += kTokStrip) {
         const uint32_t left = count - base;
         const uint32_t take = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
+        __syncthreads();
         for (uint32_t k = lane; k < take; k += kWave) { lds.strip[k] = tok[base + k]; }
         __syncthreads();
-        if (lane == 0) {
-            for (uint32_t k = 0; k < take && err == 0; k++) {
-                const uint32_t t = lds.strip[k];
-                if ((t & kTokMatch) == 0) {
-                    emit_lit(w, lit, (int)(t & 0xFFu), err);
-                } else {
-                    const int len = (int)((t >> 16) & 0x1FFu);
-                    const int dist = (int)(t & 0x7FFFu);
-                    const Code lc = len_code(len);        // squeeze.h:290-298
-                    emit_lit(w, lit, kSymLen0 + lc.code, err);
-                    if (lc.xbits > 0) { w.put_lsb((uint32_t)lc.extra, lc.xbits); }
-                    const Code pc = pos_code(dist);       // squeeze.h:300-315
-                    if (pos.link[pc.code].bits == 0) {
-                        emit_symbol(w, pos, kPosNyt);
-                        w.put_lsb((uint32_t)pc.code, 5);
-                        if (!pos.insert(pc.code)) { err = kE2BIG; }
-                    } else {
-                        emit_symbol(w, pos, pc.code);
-                    }
-                    if (pc.xbits > 0) { w.put_lsb((uint32_t)pc.extra, pc.xbits); }
-                }
-                if (w.error != 0) { err = w.error; }
-                if (lit.fault | pos.fault) { err = kE2BIG; }
+        for (uint32_t k = 0; k < take && err == 0; k++) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.strip[k]);
+            if ((t & kTokMatch) == 0) {
+                emit_coded(w, lit, (int)(t & 0xFFu), kLitNyt, 9, lane, err);
+            } else {
+                const int len = (int)((t >> 16) & 0x1FFu);
+                const int dist = (int)(t & 0x7FFFu);
+                const Code lc = len_code(len);                        // squeeze.h:290-298
+                emit_coded(w, lit, kSymLen0 + lc.code, kLitNyt, 9, lane, err);
+                if (lc.xbits > 0) { w.put_lsb((uint32_t)lc.extra, lc.xbits); }
+                const Code pc = pos_code(dist);                       // squeeze.h:300-315
+                emit_coded(w, pos, pc.code, kPosNyt, 5, lane, err);
+                if (pc.xbits > 0) { w.put_lsb((uint32_t)pc.extra, pc.xbits); }
             }
+            if (w.error != 0) { err = w.error; }
+            if (lit.fault | pos.fault) { err = kE2BIG; }
         }
-        __syncthreads();
     }
 
+    if (err == 0) { w.flush(); err = w.error; }
     if (lane == 0) {
-        if (err == 0) { w.flush(); err = w.error; }
         out_bytes[b] = w.bytes;
         err_out[b] = err;
     }
