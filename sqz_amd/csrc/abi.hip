@@ -158,6 +158,17 @@ uint64_t host_get_bits(bitstream* bs, int n) {
 
 bool window_ok(uint32_t w) { return w >= 2 && w <= 32768; }
 
+// wavefronts that share one stream's LDS window in the scan kernel (tuning knob:
+// SQZ_SCAN_WAVES=1|2|4|8, default 4 = four waves on every SIMD at 4 streams per CU)
+int scan_waves() {
+    static const int w = [] {
+        const char* e = getenv("SQZ_SCAN_WAVES");
+        const int v = e != NULL ? atoi(e) : 4;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+    }();
+    return w;
+}
+
 int check_offsets(const uint64_t* off, uint32_t n, bool need8) {
     for (uint32_t b = 0; b < n; b++) {
         if (off[b + 1] < off[b] || off[b + 1] - off[b] > kMaxStream) { return EINVAL; }
@@ -193,7 +204,7 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     {
         SpanGuard g(st, 0);
         sqzk::launch_lz77_scan((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
-                              (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, st);
+                              (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, scan_waves(), st);
     }
     {
         SpanGuard g(st, 1);
@@ -452,7 +463,7 @@ int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, 
     if (e != 0) { return e; }
     SpanGuard g((hipStream_t)stream, 0);
     sqzk::launch_lz77_scan((const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
-                          (hipStream_t)stream);
+                           scan_waves(), (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 

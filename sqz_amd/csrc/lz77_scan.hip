@@ -8,22 +8,28 @@
 // iff k >= 3 && k > best  => longest match, nearest among equals; len >= 3
 // emits a match and advances by len, otherwise a literal.
 //
-// Mapping to CDNA4: one wavefront per stream.  A sliding region of the input
-// (window + look-ahead) sits in LDS, refilled with coalesced 16-byte global
-// loads, so every input byte leaves HBM once.  Per token:
+// Mapping to CDNA4: one workgroup of W wavefronts per stream (W = 4 by default,
+// so the 4 streams that fit a CU's LDS put 4 waves on every SIMD; W = 1 is the
+// single-wavefront form).  A sliding region of the input (window + look-ahead)
+// sits in LDS, refilled with coalesced 16-byte global loads, so every input
+// byte leaves HBM once.  Per token, in every wave:
 //   * lane j keeps bytes i+4j..i+4j+3 of the string at i in a VGPR
 //     (257 look-ahead bytes = 64 lanes x 4 + 1);
-//   * the candidate sweep walks the window nearest-first, 256 positions per
-//     step: every lane reads two aligned LDS dwords and tests its 4 byte
-//     positions against the 3-byte prefix (v_perm_b32 + v_cmp), the 4 result
-//     masks land in SGPRs (__ballot) -- no hit => next step;
+//   * the candidate sweep walks the window nearest-first in steps of 256
+//     positions, wave w taking steps w, w+W, ...: every lane reads two aligned
+//     LDS dwords and tests its 4 byte positions against the 3-byte prefix
+//     (v_perm_b32 + v_cmp), the 4 result masks land in SGPRs (__ballot) --
+//     no hit => next step;
 //   * hits are first thinned in parallel (the byte at offset `best` must match,
 //     a necessary condition for k > best), survivors are extended one at a
 //     time by the whole wave: 64 dword compares + __ballot give k in one go;
-//   * the sweep stops as soon as best == min(bytes-i, 257) (the reference's
+//   * a wave stops as soon as its best == min(bytes-i, 257) (the reference's
 //     early exit at 257, squeeze.h:353; stopping at the cap is equivalent
-//     because only a strictly longer match replaces the best).
-// Tokens are collected one per lane and stored 64 at a time (256-byte rows).
+//     because only a strictly longer match replaces the best) and raises a
+//     flag the other waves poll.
+// The waves' results meet in LDS once per token (one barrier, double-buffered
+// slots): max over (len, -dist) = longest, nearest among equals.
+// Tokens are collected one per lane of wave 0 and stored 64 at a time.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
@@ -34,13 +40,24 @@ constexpr int kBack   = 288;                 // slack above the newest byte
 constexpr int kRegion = 39888;               // resident input bytes (x16)
 constexpr int kLdsBytes = kFront + kRegion + kBack;   // 40448 -> 4 streams/CU
 constexpr int kAhead  = 264;                 // look-ahead that must be resident
+constexpr int kMaxScanWaves = 8;
 
 static_assert(kRegion % 16 == 0 && kFront % 16 == 0, "16-byte staging");
 static_assert(kRegion >= kMaxWindow + kAhead + 16, "window + look-ahead must fit");
 
 struct ScanLds {
     __attribute__((aligned(16))) uint8_t buf[kLdsBytes];
+    uint32_t result[2][kMaxScanWaves];       // per token parity, per wave: len<<16 | (0xFFFF-dist)
+    uint32_t stop[2];                        // a wave reached the cap
 };
+
+// pin a wave-uniform value into SGPRs (the compiler cannot always prove it)
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
 
 __device__ __forceinline__ uint32_t lds_dword_at(const uint8_t* buf, int p) {
     // unaligned 4 bytes at byte index p from two aligned dwords
@@ -48,7 +65,8 @@ __device__ __forceinline__ uint32_t lds_dword_at(const uint8_t* buf, int p) {
     return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(p & 3));
 }
 
-__global__ __launch_bounds__(kWave)
+template <int W>
+__global__ __launch_bounds__(W * kWave)
 void lz77_scan_kernel(const uint8_t* __restrict__ in,
                       const uint64_t* __restrict__ in_off,
                       uint32_t n_blocks, uint32_t window,
@@ -56,7 +74,9 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
                       uint32_t* __restrict__ tok_count) {
     __shared__ ScanLds lds;
     uint8_t* const buf = lds.buf;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
 
@@ -65,26 +85,33 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
     uint32_t* tok = tokens + in_off[b];
     const bool src_aligned = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
 
+    if (tid < 2) { lds.stop[tid] = 0; }
+
     uint64_t base = 0;       // stream offset of buf[kFront]
     uint32_t valid = 0;      // resident bytes
     uint64_t i = 0;          // token start
     uint32_t ntok = 0;
-    uint32_t tok_reg = 0;    // lane (ntok & 63) holds the pending token
+    uint32_t tok_reg = 0;    // wave 0: lane (ntok & 63) holds the pending token
+    uint32_t par = 0;        // token parity (result slot)
 
     while (i < bytes) {
+        i = uni(i); base = uni(base); valid = uni(valid); ntok = uni(ntok); par = uni(par);
         const uint32_t reach = (uint32_t)(i < (uint64_t)(window - 1) ? i : (uint64_t)(window - 1));
 
-        // ---- keep [i-reach, i+kAhead) resident -------------------------------
+        // ---- keep [i-reach, i+kAhead) resident (all waves) --------------------
         if (i + kAhead > base + valid && base + valid < bytes) {
             const uint64_t new_base = (i - reach) & ~(uint64_t)15;
             const uint32_t shift = (uint32_t)(new_base - base);
+            if (W > 1) { __syncthreads(); }                 // everyone is done with the old image
             if (shift > 0 && shift < valid) {
                 const uint32_t keep = valid - shift;
-                for (uint32_t off = (uint32_t)lane * 16; off < keep; off += kWave * 16) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(buf + kFront + shift + off);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): reads before writes
-                    __builtin_amdgcn_wave_barrier();
-                    *reinterpret_cast<uint4*>(buf + kFront + off) = v;
+                for (uint32_t off0 = 0; off0 < keep; off0 += W * kWave * 16) {
+                    const uint32_t off = off0 + (uint32_t)tid * 16;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (off < keep) { v = *reinterpret_cast<const uint4*>(buf + kFront + shift + off); }
+                    if (W > 1) { __syncthreads(); }         // reads of this chunk before its writes
+                    else { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
+                    if (off < keep) { *reinterpret_cast<uint4*>(buf + kFront + off) = v; }
                 }
                 valid = keep;
             } else if (shift >= valid) {
@@ -97,16 +124,16 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
             const uint64_t want = (bytes - from) < room ? (bytes - from) : room;
             const uint32_t full = (uint32_t)(want & ~(uint64_t)15);
             if (src_aligned) {
-                for (uint32_t off = (uint32_t)lane * 16; off < full; off += kWave * 16) {
+                for (uint32_t off = (uint32_t)tid * 16; off < full; off += W * kWave * 16) {
                     const uint4 v = *reinterpret_cast<const uint4*>(src + from + off);
                     *reinterpret_cast<uint4*>(buf + kFront + valid + off) = v;
                 }
             } else {
-                for (uint32_t off = (uint32_t)lane; off < full; off += kWave) {
+                for (uint32_t off = (uint32_t)tid; off < full; off += W * kWave) {
                     buf[kFront + valid + off] = src[from + off];
                 }
             }
-            for (uint32_t off = full + (uint32_t)lane; off < (uint32_t)want; off += kWave) {
+            for (uint32_t off = full + (uint32_t)tid; off < (uint32_t)want; off += W * kWave) {
                 buf[kFront + valid + off] = src[from + off];
             }
             valid += (uint32_t)want;
@@ -118,8 +145,10 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
         const uint32_t cap = n_left < (uint64_t)kLenMax ? (uint32_t)n_left : (uint32_t)kLenMax;
 
         uint32_t best_len = 0, best_dist = 0;
+        bool searched = false;
 
         if (cap >= (uint32_t)kLenMin && reach >= 1) {
+            searched = true;
             // string at i: lane j holds bytes 4j..4j+3
             const uint32_t tgt = lds_dword_at(buf, li + 4 * lane);
             const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)tgt) & 0x00FFFFFFu;
@@ -130,29 +159,29 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
             const int steps = (a0 + 3 - far_p) / 256 + 1;
             bool done = false;
 
-            for (int t = 0; t < steps && !done; t++) {
-                const int a = a0 - 4 * (64 * t + lane);       // this lane's 4 positions
+            // one step: this lane's 4 positions a..a+3 against the 3-byte prefix
+            auto probe = [&](int a, bool (&c)[4]) {
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(buf + a);
                 const uint32_t lo = w[0], hi = w[1];
-                const bool c0 = __builtin_amdgcn_perm(hi, lo, 0x0c020100u) == T;
-                const bool c1 = __builtin_amdgcn_perm(hi, lo, 0x0c030201u) == T;
-                const bool c2 = __builtin_amdgcn_perm(hi, lo, 0x0c040302u) == T;
-                const bool c3 = __builtin_amdgcn_perm(hi, lo, 0x0c050403u) == T;
-                if (__ballot(c0 | c1 | c2 | c3) == 0) { continue; }
+                c[0] = __builtin_amdgcn_perm(hi, lo, 0x0c020100u) == T;
+                c[1] = __builtin_amdgcn_perm(hi, lo, 0x0c030201u) == T;
+                c[2] = __builtin_amdgcn_perm(hi, lo, 0x0c040302u) == T;
+                c[3] = __builtin_amdgcn_perm(hi, lo, 0x0c050403u) == T;
+            };
 
-                // ---- some lane sees the 3-byte prefix -----------------------
+            // some lane of step t saw the prefix: validate, thin, extend
+            auto settle = [&](int t, int a, const bool (&c)[4]) {
                 // drop positions outside [far_p, near_p]; thin by the byte at
                 // offset best_len (needed for a strictly longer match)
-                bool h[4] = { c0, c1, c2, c3 };
                 uint32_t want_byte = 0;
                 if (best_len >= (uint32_t)kLenMin) {     // best_len < cap <= 257
-                    want_byte = (uint32_t)__builtin_amdgcn_readfirstlane((int)buf[li + (int)best_len]);
+                    want_byte = uni((uint32_t)buf[li + (int)best_len]);
                 }
                 uint64_t m[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int p = a + s;
-                    bool ok = h[s] && p >= far_p && p <= near_p;
+                    bool ok = c[s] && p >= far_p && p <= near_p;
                     if (best_len >= (uint32_t)kLenMin) {
                         ok = ok && (buf[ok ? p + (int)best_len : li] == want_byte);
                     }
@@ -171,9 +200,7 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
                         const uint64_t ne = __ballot(x != 0);
                         uint32_t k;
                         if (ne == 0) {
-                            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(
-                                (int)(buf[p + 256] == buf[li + 256]));
-                            k = 256 + e;
+                            k = 256 + uni((uint32_t)(buf[p + 256] == buf[li + 256]));
                         } else {
                             const int fl = __builtin_ctzll(ne);
                             const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
@@ -183,11 +210,72 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
                         if (k > best_len) {                   // k >= 3 by the prefix test
                             best_len = k;
                             best_dist = (uint32_t)(li - p);
-                            if (best_len == cap) { done = true; }
+                            if (best_len == cap) {
+                                done = true;
+                                if (W > 1 && lane == 0) { lds.stop[par] = 1; }
+                            }
                         }
                     }
                 }
+            };
+
+            // sweep: 4 steps per trip, the LDS reads of a trip issue together
+            int t = wave;
+            const int my_a = a0 - 4 * lane;
+            while (t + 3 * W < steps && !done) {
+                bool c[4][4];
+                const int ab = my_a - 256 * t;
+                uint32_t stop_now = 0;
+                if (W > 1) { stop_now = lds.stop[par]; }      // another wave hit the cap?
+#pragma unroll
+                for (int j = 0; j < 4; j++) { probe(ab - 256 * W * j, c[j]); }
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { hit = hit | c[j][0] | c[j][1] | c[j][2] | c[j][3]; }
+                if (__ballot(hit) != 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!done && __ballot(c[j][0] | c[j][1] | c[j][2] | c[j][3]) != 0) {
+                            settle(t + W * j, ab - 256 * W * j, c[j]);
+                        }
+                    }
+                    best_len = uni(best_len);
+                    best_dist = uni(best_dist);
+                    done = uni((uint32_t)done) != 0;
+                }
+                t += 4 * W;
+                if (W > 1 && uni(stop_now) != 0) { done = true; }
             }
+            for (; t < steps && !done; t += W) {
+                bool c[4];
+                const int a = my_a - 256 * t;
+                probe(a, c);
+                if (__ballot(c[0] | c[1] | c[2] | c[3]) != 0) {
+                    settle(t, a, c);
+                    best_len = uni(best_len);
+                    best_dist = uni(best_dist);
+                    done = uni((uint32_t)done) != 0;
+                }
+            }
+        }
+
+        // ---- the waves' results meet (longest, then nearest) -------------------
+        if (W > 1 && searched) {
+            if (lane == 0) {
+                lds.result[par][wave] = best_len != 0 ? ((best_len << 16) | (0xFFFFu - best_dist)) : 0u;
+            }
+            if (tid == 0) { lds.stop[par ^ 1] = 0; }          // next token's flag
+            __syncthreads();
+            uint32_t key = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < W; w2++) {
+                const uint32_t r = lds.result[par][w2];
+                key = r > key ? r : key;
+            }
+            key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+            best_len = key >> 16;
+            best_dist = 0xFFFFu - (key & 0xFFFFu);
+            par ^= 1;
         }
 
         // ---- greedy step: squeeze.h:377-394 -----------------------------------
@@ -199,21 +287,41 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
             word = (uint32_t)__builtin_amdgcn_readfirstlane((int)buf[li]);
             i += 1;
         }
-        if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
+        if (wave == 0) {
+            if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
+            if (((ntok + 1) & 63u) == 0) { tok[ntok - 63 + lane] = tok_reg; }
+        }
         ntok++;
-        if ((ntok & 63u) == 0) { tok[ntok - 64 + lane] = tok_reg; }
     }
 
-    if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
-    if (lane == 0) { tok_count[b] = ntok; }
+    if (wave == 0) {
+        if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
+        if (lane == 0) { tok_count[b] = ntok; }
+    }
 }
 
 void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                       uint32_t window, uint32_t* tokens, uint32_t* tok_count,
-                      hipStream_t stream) {
+                      int waves_per_stream, hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(lz77_scan_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       in, in_off, n_blocks, window, tokens, tok_count);
+    switch (waves_per_stream) {
+    case 1:
+        hipLaunchKernelGGL(lz77_scan_kernel<1>, dim3(n_blocks), dim3(kWave), 0, stream,
+                           in, in_off, n_blocks, window, tokens, tok_count);
+        break;
+    case 2:
+        hipLaunchKernelGGL(lz77_scan_kernel<2>, dim3(n_blocks), dim3(2 * kWave), 0, stream,
+                           in, in_off, n_blocks, window, tokens, tok_count);
+        break;
+    case 8:
+        hipLaunchKernelGGL(lz77_scan_kernel<8>, dim3(n_blocks), dim3(8 * kWave), 0, stream,
+                           in, in_off, n_blocks, window, tokens, tok_count);
+        break;
+    default:
+        hipLaunchKernelGGL(lz77_scan_kernel<4>, dim3(n_blocks), dim3(4 * kWave), 0, stream,
+                           in, in_off, n_blocks, window, tokens, tok_count);
+        break;
+    }
 }
 
 } // namespace sqzk

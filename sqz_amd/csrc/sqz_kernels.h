@@ -10,9 +10,10 @@ namespace sqzk {
 // (attic/map_experiment/squeeze.h:338-358, :377-394).  Block b reads
 // in[in_off[b] .. in_off[b+1]) and writes its token words at
 // tokens + in_off[b]; the count goes to tok_count[b].
+// waves_per_stream: 1, 2, 4 (default) or 8 wavefronts share one stream's window.
 void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                       uint32_t window, uint32_t* tokens, uint32_t* tok_count,
-                      hipStream_t stream);
+                      int waves_per_stream, hipStream_t stream);
 
 // stage 2: adaptive-Huffman emit (squeeze.h:278-315, huffman.h, bitstream.h)
 void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
