@@ -166,11 +166,24 @@ SQZ_API int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, ui
 SQZ_API int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
                                 uint32_t window, uint32_t* d_tokens,
                                 uint32_t* d_token_count, void* stream);
+/* stage 1 with an explicit match finder: 0 = brute-force scan (squeeze.h:340-358 as
+ * written), 1 = indexed (same tokens; visits only the earlier positions that share
+ * the 3-byte prefix, nearest first -- SURVEY.md section 8f-3).  finder 1 needs
+ * d_work = 8 bytes per input byte (+512).                                        */
+SQZ_API int sqz_hip_lz77_blocks_ex(const void* d_in, const uint64_t* d_in_off, uint32_t n,
+                                   uint32_t window, uint32_t* d_tokens,
+                                   uint32_t* d_token_count, int finder,
+                                   void* d_work, uint64_t work_bytes, void* stream);
 SQZ_API int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
                                    const uint32_t* d_token_count, uint32_t n,
                                    void* d_out, const uint64_t* d_out_off,
                                    uint64_t* d_out_bytes, int32_t* d_err,
                                    void* stream);
+
+/* which finder sqz_compress / sqz_*encode_blocks use: 1 = indexed (default),
+ * 0 = brute-force scan; also settable with SQZ_FINDER=scan|index.           */
+SQZ_API void sqz_hip_set_finder(int finder);
+SQZ_API int  sqz_hip_get_finder(void);
 
 /* Live timing of the last kernels enqueued through this library on the
  * calling thread's context, measured with HIP events ON THE LAUNCH STREAM.

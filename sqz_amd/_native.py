@@ -65,7 +65,11 @@ PROTOTYPES = {
                                         _vp, C.c_uint64, _vp]),
     "sqz_hip_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     "sqz_hip_lz77_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "sqz_hip_lz77_blocks_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int, _vp,
+                                         C.c_uint64, _vp]),
     "sqz_hip_huffman_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sqz_hip_set_finder": (None, [C.c_int]),
+    "sqz_hip_get_finder": (C.c_int, []),
     "sqz_hip_set_timing": (None, [C.c_int]),
     "sqz_hip_get_timing": (C.c_int, [C.POINTER(Timing), C.c_int]),
     "sqz_hip_zipf_blocks": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),

@@ -56,14 +56,25 @@ class Encoder:
             _stream()), "sqz_hip_encode_blocks")
         return self.out, self.out_off, self.out_bytes, self.err
 
-    def tokens(self, d_in, in_off, window: int):
-        """stage 1 alone: (tokens int32[total], counts int32[n])."""
+    def tokens(self, d_in, in_off, window: int, finder: str = "index"):
+        """stage 1 alone: (tokens int32[total], counts int32[n]).
+
+        finder: "scan" = brute force as the reference writes it, "index" = same
+        tokens through the sorted 3-byte-prefix index."""
         total = int(in_off[-1].item())
         toks = torch.zeros(total + 64, dtype=torch.int32, device=self.device)
         counts = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-        _raise(N.lib().sqz_hip_lz77_blocks(_ptr(d_in), _ptr(in_off), self.n, window,
-                                            _ptr(toks), _ptr(counts), _stream()),
-               "sqz_hip_lz77_blocks")
+        if finder == "scan":
+            _raise(N.lib().sqz_hip_lz77_blocks(_ptr(d_in), _ptr(in_off), self.n, window,
+                                                _ptr(toks), _ptr(counts), _stream()),
+                   "sqz_hip_lz77_blocks")
+        else:
+            work = torch.empty(8 * (total + 64), dtype=torch.uint8, device=self.device)
+            _raise(N.lib().sqz_hip_lz77_blocks_ex(_ptr(d_in), _ptr(in_off), self.n, window,
+                                                   _ptr(toks), _ptr(counts), 1, _ptr(work),
+                                                   work.numel(), _stream()),
+                   "sqz_hip_lz77_blocks_ex")
+            torch.cuda.synchronize()
         return toks, counts
 
 
@@ -74,6 +85,11 @@ def decode_blocks(d_comp, comp_off, n_blocks, d_out, out_off, err=None):
                                           _ptr(out_off), _ptr(err), _stream()),
            "sqz_hip_decode_blocks")
     return err
+
+
+def set_finder(name: str):
+    """"index" (default) or "scan" (brute force, the reference's loop as written)."""
+    N.lib().sqz_hip_set_finder(0 if name == "scan" else 1)
 
 
 def set_timing(on: bool):

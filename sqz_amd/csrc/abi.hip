@@ -44,7 +44,7 @@ struct Ctx {
     int  cus = 0;
     uint64_t lds = 0;
     // staging pool of the host-buffer flavour (grow-only, guarded by mu)
-    DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit;
+    DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit, work_a, work_m;
 };
 
 Ctx& ctx() { static Ctx c; return c; }
@@ -179,6 +179,37 @@ int check_offsets(const uint64_t* off, uint32_t n, bool need8) {
 
 uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// match finder of encode stage 1: 1 = indexed (default), 0 = brute-force scan
+// (SQZ_FINDER=scan|index).  Both produce the reference's tokens.
+int g_finder = -1;      // -1 = not chosen yet
+int finder_default() {
+    if (g_finder < 0) {
+        const char* e = getenv("SQZ_FINDER");
+        g_finder = (e != NULL && strcmp(e, "scan") == 0) ? 0 : 1;
+    }
+    return g_finder;
+}
+
+uint32_t match_groups_for(uint64_t avg_block_bytes) {
+    uint64_t g = (avg_block_bytes + 1023) / 1024;
+    if (g < 1) { g = 1; }
+    if (g > 65535) { g = 65535; }
+    return (uint32_t)g;
+}
+
+// stage 1 on device buffers; work = 2 arrays of one uint32 slot per input byte
+void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
+                uint32_t window, uint32_t* tokens, uint32_t* counts,
+                uint32_t* work_a, uint32_t* work_m, uint64_t avg_block, hipStream_t st) {
+    SpanGuard g(st, 0);
+    if (finder == 0 || work_a == nullptr || work_m == nullptr) {
+        sqzk::launch_lz77_scan(d_in, d_in_off, n, window, tokens, counts, scan_waves(), st);
+    } else {
+        sqzk::launch_lz77_index(d_in, d_in_off, n, window, work_a, tokens /* = buf_b */, work_m,
+                                tokens, counts, match_groups_for(avg_block), st);
+    }
+}
+
 // host-buffer encode of n blocks; prefix = pending header bits of block 0
 // (single-stream API only).  Caller holds ctx().mu.
 int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32_t n,
@@ -194,6 +225,7 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     if ((e = c.in.reserve(total_in + 16)) || (e = c.out.reserve(total_out + 16)) ||
         (e = c.in_off.reserve((n + 1) * 8)) || (e = c.out_off.reserve((n + 1) * 8)) ||
         (e = c.tokens.reserve((total_in + 64) * 4)) || (e = c.tok_count.reserve((size_t)n * 4)) ||
+        (e = c.work_a.reserve((total_in + 64) * 4)) || (e = c.work_m.reserve((total_in + 64) * 4)) ||
         (e = c.out_bytes.reserve((size_t)n * 8)) || (e = c.err.reserve((size_t)n * 4))) {
         return e;
     }
@@ -201,11 +233,11 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     if (total_in > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in + in_base, total_in, hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-    {
-        SpanGuard g(st, 0);
-        sqzk::launch_lz77_scan((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
-                              (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, scan_waves(), st);
-    }
+    uint64_t widest = 0;
+    for (uint32_t b = 0; b < n; b++) { widest = io[b + 1] - io[b] > widest ? io[b + 1] - io[b] : widest; }
+    run_stage1(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
+               (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
+               (uint32_t*)c.work_m.p, widest, st);
     {
         SpanGuard g(st, 1);
         sqzk::launch_huffman_emit((const uint32_t*)c.tokens.p, (const uint64_t*)c.in_off.p,
@@ -445,7 +477,9 @@ int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
 
 // ------------------------------------------------------------------ batch, device
 uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes) {
-    return align_up((uint64_t)n * 4, 256) + (total_in_bytes + 64) * 4;
+    // token counts + three uint32 slots per input byte (tokens / sort ping-pong, sorted
+    // positions, match table)
+    return align_up((uint64_t)n * 4, 256) + 3 * (total_in_bytes + 64) * 4;
 }
 
 static int device_ready(void) {
@@ -461,9 +495,27 @@ int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, 
         !window_ok(window)) { return EINVAL; }
     const int e = device_ready();
     if (e != 0) { return e; }
-    SpanGuard g((hipStream_t)stream, 0);
-    sqzk::launch_lz77_scan((const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
-                           scan_waves(), (hipStream_t)stream);
+    run_stage1(0, (const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
+               nullptr, nullptr, 0, (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+int sqz_hip_lz77_blocks_ex(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
+                           uint32_t* d_tokens, uint32_t* d_token_count, int finder,
+                           void* d_work, uint64_t work_bytes, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_in == NULL || d_in_off == NULL || d_tokens == NULL || d_token_count == NULL ||
+        !window_ok(window) || (finder != 0 && finder != 1)) { return EINVAL; }
+    if (finder == 1 && (d_work == NULL || work_bytes < 8 * 64)) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    // work = two arrays of work_bytes/8 uint32 slots (sorted positions, match table)
+    const uint64_t slots = work_bytes / 8;
+    uint32_t* wa = (uint32_t*)d_work;
+    uint32_t* wm = wa != nullptr ? wa + slots : nullptr;
+    run_stage1(finder, (const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
+               finder == 1 ? wa : nullptr, finder == 1 ? wm : nullptr,
+               slots / (n > 0 ? n : 1), (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
@@ -487,9 +539,18 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
                           int32_t* d_err, void* d_scratch, uint64_t scratch_bytes, void* stream) {
     if (n == 0) { return 0; }
     if (d_scratch == NULL || scratch_bytes < sqz_hip_encode_scratch_bytes(n, 0)) { return EINVAL; }
+    if (d_in == NULL || d_in_off == NULL || !window_ok(window)) { return EINVAL; }
+    int e = device_ready();
+    if (e != 0) { return e; }
+    const uint64_t head = align_up((uint64_t)n * 4, 256);
+    const uint64_t slots = (scratch_bytes - head) / 12;    // >= total_in_bytes + 64 by contract
     uint32_t* counts = (uint32_t*)d_scratch;
-    uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + align_up((uint64_t)n * 4, 256));
-    int e = sqz_hip_lz77_blocks(d_in, d_in_off, n, window, tokens, counts, stream);
+    uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + head);
+    uint32_t* work_a = tokens + slots;
+    uint32_t* work_m = work_a + slots;
+    run_stage1(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
+               work_a, work_m, slots / n, (hipStream_t)stream);
+    e = hip_errno(hipGetLastError());
     if (e != 0) { return e; }
     return sqz_hip_huffman_blocks(tokens, d_in_off, counts, n, d_out, d_out_off, d_out_bytes,
                                   d_err, stream);
@@ -508,6 +569,9 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
                        n, 0, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
+
+void sqz_hip_set_finder(int finder) { g_finder = finder == 0 ? 0 : 1; }
+int  sqz_hip_get_finder(void) { return finder_default(); }
 
 // ------------------------------------------------------------------ timing
 void sqz_hip_set_timing(int enabled) {

@@ -1,0 +1,283 @@
+// sqz_amd/csrc/lz77_index.hip -- encode stage 1, indexed form (gfx950).
+//
+// Same result as the brute-force scan of lz77_scan.hip (and therefore as the
+// reference, attic/map_experiment/squeeze.h:338-358,377-394), found without
+// visiting every distance: a candidate can only matter if it shares the first
+// 3 bytes with the string at i (squeeze_deflate_len_min = 3, squeeze.h:13), so
+// it is enough to visit, nearest first, the earlier positions with the same
+// 3-byte prefix.  This is SURVEY.md section 8f-3 ("faster exact match
+// finders ... every in-window candidate sharing the 3-byte prefix visited
+// nearest-first with strict >"), validated like bst.c:254-308 validates its
+// finder: token-for-token equality with the brute-force scan (tests).
+//
+// Three kernels, all data parallel except the last:
+//   index_sort_kernel   one 1024-thread workgroup per stream: stable LSD radix
+//                       sort (3 passes x 8 bits) of the positions 0..n-3 by their
+//                       3-byte prefix.  Equal prefixes end up adjacent, positions
+//                       ascending inside a run.
+//   index_match_kernel  one thread per position (all positions, not only token
+//                       starts -- there is no serial dependence here): walk the
+//                       run backwards = nearest first, stop at distance
+//                       min(i, window-1), keep the first strictly longer match,
+//                       stop at len == min(bytes-i, 257).  -> match[i]
+//   index_parse_kernel  one wavefront per stream: the greedy step
+//                       (squeeze.h:377-394) over match[] -> the token words of
+//                       stage 1 (same format as lz77_scan.hip).
+#include "sqz_device.h"
+#include "sqz_kernels.h"
+
+namespace sqzk {
+
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / kWave;
+
+struct SortLds {
+    uint32_t cnt[kSortWaves][256];   // per wave, per digit: running destination
+    uint32_t total[256];
+};
+
+struct __attribute__((packed)) U32u { uint32_t v; };
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+    return reinterpret_cast<const U32u*>(p)->v;
+}
+
+// lanes of this wave with the same 8-bit digit (and valid), as a 64-bit mask
+__device__ __forceinline__ uint64_t peers_of(uint32_t digit, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const bool set = (digit >> bit) & 1u;
+        const uint64_t m = __ballot(set);
+        peers &= set ? m : ~m;
+    }
+    return peers;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {   // popcount of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(kSortThreads)
+void index_sort_kernel(const uint8_t* __restrict__ in,
+                       const uint64_t* __restrict__ in_off,
+                       uint32_t n_blocks,
+                       uint32_t* __restrict__ buf_a,      // result lands here
+                       uint32_t* __restrict__ buf_b) {
+    __shared__ SortLds lds;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const uint8_t* src = in + in_off[b];
+    const uint64_t bytes = in_off[b + 1] - in_off[b];
+    if (bytes < 3) { return; }
+    const uint32_t count = (uint32_t)(bytes - 2);             // positions with a 3-byte prefix
+    uint32_t* const pa = buf_a + in_off[b];
+    uint32_t* const pb = buf_b + in_off[b];
+
+    // each wave owns a contiguous slice (keeps the scatter stable without
+    // workgroup barriers inside the sweep)
+    const uint32_t slice = (((count + kSortWaves - 1) / kSortWaves) + 63u) & ~63u;
+    const uint32_t lo = (uint32_t)wave * slice < count ? (uint32_t)wave * slice : count;
+    const uint32_t hi = lo + slice < count ? lo + slice : count;
+
+    for (int pass = 0; pass < 3; pass++) {
+        // pass 0: identity -> A by byte 2 ; pass 1: A -> B by byte 1 ; pass 2: B -> A by byte 0
+        const uint32_t* from = pass == 1 ? pa : pb;
+        uint32_t* to = pass == 1 ? pb : pa;
+        const int byte_ix = 2 - pass;
+
+        for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
+        // ---- count ----------------------------------------------------------
+        for (uint32_t e = lo; e < hi; e += kWave) {
+            const uint32_t k = e + (uint32_t)lane;
+            const bool valid = k < hi;
+            uint32_t pos = 0, digit = 0;
+            if (valid) {
+                pos = pass == 0 ? k : from[k];
+                digit = src[pos + byte_ix];
+            }
+            const uint64_t peers = peers_of(digit, valid);
+            if (valid && lanes_below(peers) == 0) {
+                lds.cnt[wave][digit] += (uint32_t)__builtin_popcountll(peers);
+            }
+        }
+        __syncthreads();
+        // ---- offsets: digit-major, then wave order inside a digit -------------
+        if (tid < 256) {
+            uint32_t run = 0;
+            for (int w = 0; w < kSortWaves; w++) {
+                const uint32_t c = lds.cnt[w][tid];
+                lds.cnt[w][tid] = run;
+                run += c;
+            }
+            lds.total[tid] = run;
+        }
+        __syncthreads();
+        if (wave == 0) {                                   // exclusive scan of 256 totals
+            uint32_t v[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[j] = lds.total[4 * lane + j]; s += v[j]; }
+            uint32_t incl = s;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= d) { incl += up; }
+            }
+            uint32_t excl = incl - s;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { lds.total[4 * lane + j] = excl; excl += v[j]; }
+        }
+        __syncthreads();
+        for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] += lds.total[d]; }
+        // ---- stable scatter (wave-private counters: no barrier needed) -------
+        for (uint32_t e = lo; e < hi; e += kWave) {
+            const uint32_t k = e + (uint32_t)lane;
+            const bool valid = k < hi;
+            uint32_t pos = 0, digit = 0;
+            if (valid) {
+                pos = pass == 0 ? k : from[k];
+                digit = src[pos + byte_ix];
+            }
+            const uint64_t peers = peers_of(digit, valid);
+            const uint32_t rank = lanes_below(peers);
+            uint32_t dest = 0;
+            if (valid) { dest = lds.cnt[wave][digit] + rank; }
+            __builtin_amdgcn_wave_barrier();               // all reads before the leaders' writes
+            if (valid && rank == 0) {
+                lds.cnt[wave][digit] += (uint32_t)__builtin_popcountll(peers);
+            }
+            if (valid) { to[dest] = pos; }
+        }
+        // the next pass reads what other waves of this workgroup wrote
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void index_match_kernel(const uint8_t* __restrict__ in,
+                        const uint64_t* __restrict__ in_off,
+                        uint32_t n_blocks, uint32_t window,
+                        const uint32_t* __restrict__ sorted,
+                        uint32_t* __restrict__ match) {
+    const uint32_t b = blockIdx.x;                        // stream; blockIdx.y = group inside it
+    if (b >= n_blocks) { return; }
+    const uint8_t* src = in + in_off[b];
+    const uint64_t bytes = in_off[b + 1] - in_off[b];
+    if (bytes < 3) { return; }
+    const uint32_t n = (uint32_t)bytes;
+    const uint32_t count = n - 2;
+    const uint32_t* S = sorted + in_off[b];
+    uint32_t* M = match + in_off[b];
+
+    for (uint32_t r = blockIdx.y * blockDim.x + threadIdx.x; r < count; r += gridDim.y * blockDim.x) {
+        const uint32_t i = S[r];
+        const uint32_t cap = (n - i) < (uint32_t)kLenMax ? (n - i) : (uint32_t)kLenMax;
+        const uint32_t reach = i < window - 1 ? i : window - 1;
+        const uint32_t key = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16);
+        uint32_t best = 0, dist = 0;
+        for (uint32_t q = r; q > 0 && best < cap; ) {
+            q--;
+            const uint32_t p = S[q];                       // p < i inside a run
+            if (i - p > reach) { break; }                  // everything further is farther
+            const uint32_t pk = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+            if (pk != key) { break; }                      // left the run
+            if (best >= (uint32_t)kLenMin && src[p + best] != src[i + best]) { continue; }
+            uint32_t k = 3;
+            while (k < cap) {
+                if (i + k + 4 <= n) {
+                    const uint32_t x = load_u32_unaligned(src + p + k) ^ load_u32_unaligned(src + i + k);
+                    if (x != 0) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                    k += 4;
+                } else {
+                    if (src[p + k] != src[i + k]) { break; }
+                    k++;
+                }
+            }
+            if (k > cap) { k = cap; }
+            if (k > best) { best = k; dist = i - p; }      // strictly longer: nearest among equals
+        }
+        M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kParseStrip = 512;
+
+struct ParseLds {
+    uint32_t m[kParseStrip];
+    __attribute__((aligned(4))) uint8_t d[kParseStrip];
+};
+
+__global__ __launch_bounds__(kWave)
+void index_parse_kernel(const uint8_t* __restrict__ in,
+                        const uint64_t* __restrict__ in_off,
+                        uint32_t n_blocks,
+                        const uint32_t* __restrict__ match,
+                        uint32_t* __restrict__ tokens,
+                        uint32_t* __restrict__ tok_count) {
+    __shared__ ParseLds lds;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }
+    const int lane = threadIdx.x;
+    const uint8_t* src = in + in_off[b];
+    const uint64_t bytes = in_off[b + 1] - in_off[b];
+    const uint32_t* M = match + in_off[b];
+    uint32_t* tok = tokens + in_off[b];
+
+    uint64_t i = 0, sbase = 0;
+    uint32_t have = 0;                  // strip covers [sbase, sbase + have)
+    uint32_t ntok = 0, tok_reg = 0;
+    while (i < bytes) {
+        if (i >= sbase + have) {        // (re)load the strip at i
+            sbase = i;
+            const uint64_t left = bytes - sbase;
+            have = left < (uint64_t)kParseStrip ? (uint32_t)left : (uint32_t)kParseStrip;
+            __syncthreads();
+            for (uint32_t k = lane; k < have; k += kWave) {
+                // positions bytes-2, bytes-1 have no 3-byte prefix: literal
+                lds.m[k] = (sbase + k + 2 < bytes) ? M[sbase + k] : 0u;
+                lds.d[k] = src[sbase + k];
+            }
+            __syncthreads();
+        }
+        const uint32_t at = (uint32_t)(i - sbase);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.m[at]);
+        uint32_t word;
+        if (m != 0) {
+            word = kTokMatch | m;
+            i += m >> 16;
+        } else {
+            word = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.d[at]);
+            i += 1;
+        }
+        if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
+        ntok++;
+        if ((ntok & 63u) == 0) { tok[ntok - 64 + lane] = tok_reg; }
+    }
+    if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
+    if (lane == 0) { tok_count[b] = ntok; }
+}
+
+void launch_lz77_index(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                       uint32_t window, uint32_t* buf_a, uint32_t* buf_b, uint32_t* match,
+                       uint32_t* tokens, uint32_t* tok_count, uint32_t match_groups,
+                       hipStream_t stream) {
+    if (n_blocks == 0) { return; }
+    hipLaunchKernelGGL(index_sort_kernel, dim3(n_blocks), dim3(kSortThreads), 0, stream,
+                       in, in_off, n_blocks, buf_a, buf_b);
+    if (match_groups < 1) { match_groups = 1; }
+    if (match_groups > 65535) { match_groups = 65535; }
+    hipLaunchKernelGGL(index_match_kernel, dim3(n_blocks, match_groups), dim3(256), 0, stream,
+                       in, in_off, n_blocks, window, buf_a, match);
+    hipLaunchKernelGGL(index_parse_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
+                       in, in_off, n_blocks, match, tokens, tok_count);
+}
+
+} // namespace sqzk

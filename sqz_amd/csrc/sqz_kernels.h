@@ -15,6 +15,14 @@ void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_bloc
                       uint32_t window, uint32_t* tokens, uint32_t* tok_count,
                       int waves_per_stream, hipStream_t stream);
 
+// stage 1, indexed form: same tokens as launch_lz77_scan without visiting every
+// distance (lz77_index.hip).  buf_a / buf_b / match: one uint32 slot per input
+// byte each, addressed like `tokens` (buf_b may alias tokens).
+void launch_lz77_index(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                       uint32_t window, uint32_t* buf_a, uint32_t* buf_b, uint32_t* match,
+                       uint32_t* tokens, uint32_t* tok_count, uint32_t match_groups,
+                       hipStream_t stream);
+
 // stage 2: adaptive-Huffman emit (squeeze.h:278-315, huffman.h, bitstream.h)
 void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          const uint32_t* tok_count, uint8_t* out,

@@ -119,28 +119,48 @@ def test_window_sweep(sq, batch, window):
     assert outs[0] == O.encode(data, 15, header=False, window=window)
 
 
-def test_tokens_vs_oracle(sq, batch):
-    """stage 1 alone (bst.c differential pattern: the GPU finder equals brute force
-    at every token start) + golden token dump."""
+@pytest.mark.parametrize("finder", ["index", "scan"])
+def test_tokens_vs_oracle(sq, batch, finder):
+    """stage 1 alone, both finders (the bst.c:254-308 differential pattern: every
+    finder must equal brute force at every token start) + the golden token dump."""
     import torch
+    rng = random.Random(17)
     blocks = [O.corpus("laozi.txt"), O.zipf_block(3, 20000), bytes(3000) + b"abc" * 700,
-              O.corpus("confucius.txt")[:30000]]
+              O.corpus("confucius.txt")[:30000], b"", b"ab", b"abc", b"abcabc",
+              bytes(rng.choice(b"ab") for _ in range(5000)), bytes(70000),
+              O.corpus("x64.elf")[4096:4096 + 50000]]
     sizes = [len(b) for b in blocks]
     off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device="cuda")
-    d_in = torch.tensor(np.frombuffer(b"".join(blocks), np.uint8), device="cuda")
+    d_in = torch.tensor(np.frombuffer(b"".join(blocks), np.uint8).copy(), device="cuda")
     enc = batch.Encoder(len(blocks), sum(sizes), sq.bound(max(sizes)))
-    for window in (1 << 15, 1 << 11):
-        toks, counts = enc.tokens(d_in, off, window)
+    for window in (1 << 15, 1 << 11, 5):
+        toks, counts = enc.tokens(d_in, off, window, finder=finder)
         torch.cuda.synchronize()
         toks = toks.cpu().numpy().view(np.uint32)
         for b, data in enumerate(blocks):
             want = O.tokens(data, window)
-            assert int(counts[b]) == len(want)
+            assert int(counts[b]) == len(want), (b, window)
             got = toks[int(off[b]):int(off[b]) + len(want)]
             assert (got == want).all(), (b, window)
     want = np.load(os.path.join(O.GOLD, "laozi_tokens_w15.npy"))
-    toks, counts = enc.tokens(d_in, off, 1 << 15)
+    toks, counts = enc.tokens(d_in, off, 1 << 15, finder=finder)
     assert (toks.cpu().numpy().view(np.uint32)[:len(want)] == want).all()
+
+
+def test_scan_finder_end_to_end(sq, batch):
+    """the brute-force scan (north_star's O(window) form) through the whole encode"""
+    batch.set_finder("scan")
+    try:
+        cases = _rand_cases(2)[:24] + [O.corpus("laozi.txt")]
+        outs, err = batch.encode_blocks_host(cases, 1 << 12)
+        assert not err.any()
+        for data, got in zip(cases, outs):
+            assert got == O.encode(data, 12, header=False)
+        data = O.corpus("confucius.txt")
+        with open(os.path.join(O.GOLD, "confucius.txt.w15.sqz"), "rb") as fh:
+            assert sq.compress(data, win_bits=15, header=True) == fh.read()
+    finally:
+        batch.set_finder("index")
 
 
 def test_zipf_batch_vs_oracle(sq, batch):
