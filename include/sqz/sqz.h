@@ -153,9 +153,11 @@ SQZ_API int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, ui
                                   uint64_t* d_out_bytes, int32_t* d_err,
                                   void* d_scratch, uint64_t scratch_bytes,
                                   void* stream);
+SQZ_API uint64_t sqz_hip_decode_scratch_bytes(uint32_t n, uint64_t total_out_bytes);
 SQZ_API int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
                                   void* d_out, const uint64_t* d_out_off,
-                                  int32_t* d_err, void* stream);
+                                  int32_t* d_err, void* d_scratch, uint64_t scratch_bytes,
+                                  void* stream);
 
 /* The two encode stages on their own (parity tests pin each independently,
  * SURVEY.md section 8c; also what a caller with its own entropy stage binds):

@@ -63,7 +63,8 @@ PROTOTYPES = {
     "sqz_hip_encode_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
     "sqz_hip_encode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
                                         _vp, C.c_uint64, _vp]),
-    "sqz_hip_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "sqz_hip_decode_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
+    "sqz_hip_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "sqz_hip_lz77_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "sqz_hip_lz77_blocks_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int, _vp,
                                          C.c_uint64, _vp]),

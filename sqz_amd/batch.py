@@ -78,12 +78,25 @@ class Encoder:
         return toks, counts
 
 
-def decode_blocks(d_comp, comp_off, n_blocks, d_out, out_off, err=None):
+_decode_scratch = {}
+
+
+def decode_blocks(d_comp, comp_off, n_blocks, d_out, out_off, err=None, scratch=None):
+    """n streams -> d_out.  scratch: uint8 tensor of sqz_hip_decode_scratch_bytes()
+    (kept per device between calls when not given)."""
+    L = N.lib()
     if err is None:
         err = torch.zeros(n_blocks, dtype=torch.int32, device=d_out.device)
-    _raise(N.lib().sqz_hip_decode_blocks(_ptr(d_comp), _ptr(comp_off), n_blocks, _ptr(d_out),
-                                          _ptr(out_off), _ptr(err), _stream()),
-           "sqz_hip_decode_blocks")
+    need = int(L.sqz_hip_decode_scratch_bytes(n_blocks, d_out.numel()))
+    if scratch is None:
+        key = str(d_out.device)
+        scratch = _decode_scratch.get(key)
+        if scratch is None or scratch.numel() < need:
+            scratch = torch.empty(need, dtype=torch.uint8, device=d_out.device)
+            _decode_scratch[key] = scratch
+    _raise(L.sqz_hip_decode_blocks(_ptr(d_comp), _ptr(comp_off), n_blocks, _ptr(d_out),
+                                   _ptr(out_off), _ptr(err), _ptr(scratch), scratch.numel(),
+                                   _stream()), "sqz_hip_decode_blocks")
     return err
 
 

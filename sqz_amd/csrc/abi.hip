@@ -277,7 +277,8 @@ int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     int e;
     if ((e = c.in.reserve(total_in + 16)) || (e = c.out.reserve(total_out + 16)) ||
         (e = c.in_off.reserve((n + 1) * 8)) || (e = c.out_off.reserve((n + 1) * 8)) ||
-        (e = c.err.reserve((size_t)n * 4)) || (e = c.end_bit.reserve((size_t)n * 8))) {
+        (e = c.err.reserve((size_t)n * 4)) || (e = c.end_bit.reserve((size_t)n * 8)) ||
+        (e = c.tokens.reserve((total_out + 64) * 4)) || (e = c.tok_count.reserve((size_t)n * 4))) {
         return e;
     }
     hipStream_t st = nullptr;
@@ -287,8 +288,9 @@ int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     {
         SpanGuard g(st, 2);
         sqzk::launch_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
-                           (const uint64_t*)c.out_off.p, (int32_t*)c.err.p,
-                           (uint64_t*)c.end_bit.p, n, start_bit, st);
+                            (const uint64_t*)c.out_off.p, (int32_t*)c.err.p,
+                            (uint64_t*)c.end_bit.p, (uint32_t*)c.tokens.p,
+                            (uint32_t*)c.tok_count.p, n, start_bit, st);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -556,17 +558,25 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
                                   d_err, stream);
 }
 
+uint64_t sqz_hip_decode_scratch_bytes(uint32_t n, uint64_t total_out_bytes) {
+    return align_up((uint64_t)n * 4, 256) + (total_out_bytes + 64) * 4;
+}
+
 int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, void* d_out,
-                          const uint64_t* d_out_off, int32_t* d_err, void* stream) {
+                          const uint64_t* d_out_off, int32_t* d_err,
+                          void* d_scratch, uint64_t scratch_bytes, void* stream) {
     if (n == 0) { return 0; }
-    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL || d_err == NULL) {
+    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL || d_err == NULL ||
+        d_scratch == NULL || scratch_bytes < sqz_hip_decode_scratch_bytes(n, 0)) {
         return EINVAL;
     }
     const int e = device_ready();
     if (e != 0) { return e; }
+    uint32_t* counts = (uint32_t*)d_scratch;
+    uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + align_up((uint64_t)n * 4, 256));
     SpanGuard g((hipStream_t)stream, 2);
     sqzk::launch_decode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_err, nullptr,
-                       n, 0, (hipStream_t)stream);
+                        tokens, counts, n, 0, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 

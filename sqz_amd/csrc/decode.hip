@@ -1,16 +1,19 @@
-// sqz_amd/csrc/decode.hip -- decoder (gfx950).
+// sqz_amd/csrc/decode.hip -- decoder (gfx950), two kernels.
 //
-// One wavefront per stream, running uniformly:
-//   squeeze.h:502-551 squeeze_decompress   token loop
-//   squeeze.h:429-442 squeeze_read_huffman root->leaf walk, then frequency bump
-//   squeeze.h:458-474 squeeze_read_length
-//   squeeze.h:476-500 squeeze_read_pos
-//   squeeze.h:537-539 byte-serial overlapped copy (RLE when dist < len)
-// The root->leaf walk hands level d of the path to lane d, so the frequency
-// update right after it is the parallel fast path of sqz_device.h (the walk has
-// already produced the chain the update needs).  Literals are byte stores by
-// lane 0; a back reference is copied by all 64 lanes with the overlap rule
-// out[i+k] = out[i-dist + (k mod dist)].
+//   entropy_decode_kernel   one wavefront per stream, running uniformly:
+//       squeeze.h:502-551 squeeze_decompress   token loop (without the copy)
+//       squeeze.h:429-442 squeeze_read_huffman root->leaf walk, then frequency bump
+//       squeeze.h:458-474 squeeze_read_length
+//       squeeze.h:476-500 squeeze_read_pos
+//     The root->leaf walk hands level d of the path to lane d, so the frequency
+//     update right after it is the parallel fast path of sqz_device.h (the walk
+//     has already produced the chain the update needs).  Output: the same token
+//     words stage 1 of the encoder produces (literal / len<<16|dist).
+//   lz_expand_kernel        one wavefront per stream: squeeze.h:521-539.  The
+//     output window lives in LDS (like the encoder's scan), 64 tokens per step:
+//     literals land in parallel, back references are copied by all 64 lanes
+//     with the byte-serial overlap rule out[i+k] = out[i-dist + (k mod dist)]
+//     (RLE when dist < len), finished bytes leave for HBM in 16-byte rows.
 //
 // Hardening (the reference only asserts): a missing
 // child, a raw symbol that is out of range or already in the tree, a distance
@@ -23,60 +26,45 @@ namespace sqzk {
 
 struct DecodeLds {
     EntropyLds entropy;
+    DecodeLuts luts;
 };
 
-// squeeze.h:429-442; returns the leaf or -1 with err set
+// squeeze.h:429-442; returns the leaf or -1 with err set.  The first 8 levels
+// of the root->leaf walk come from the lookup table (rebuilt whenever the tree
+// restructured, ~1 % of the symbols), deeper leaves continue bit by bit; the
+// leaf->root chain for the frequency update is chain_up()'s.
 template <class T>
 __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& err) {
-    int node = T::kRoot, d = 0;
-    int mine = (lane == 0) ? node : (int)kNil;
-    for (;;) {
-        const int bit = r.bit();
-        if (r.error != 0) { err = r.error; return -1; }
-        const int child = __builtin_amdgcn_readfirstlane(
-            (int)(bit ? t.link[node].hi : t.link[node].lo));
-        if (child == kNil) { err = kEINVAL; return -1; }
-        d++;
-        mine = (lane == d) ? child : mine;
-        node = child;
-        if (child < (int)T::kRoot) { break; }            // leaf ids < LEAVES
-        if (d >= kMaxFastDepth) { break; }               // finish serially below
+    if (t.lut_ok == 0) { t.build_lut(lane); }
+    r.fill();
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(8)]);
+    int node = (int)(e & 0x3FFu);
+    r.skip((int)(e >> 10));
+    int d = (int)(e >> 10);
+    while (node >= (int)T::kRoot && node != (int)kNil) {           // deeper than 8 levels
+        r.fill();
+        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 30);     // lo | hi << 10
+        node = (int)((kids >> (r.peek(1) ? 10 : 0)) & 0x3FFu);
+        r.skip(1);
+        if (++d > 2 * kStack) { node = (int)kNil; }
     }
-    if (node >= (int)T::kRoot) {                         // deeper than the wave is wide
-        for (;;) {
-            const int bit = r.bit();
-            if (r.error != 0) { err = r.error; return -1; }
-            const int child = __builtin_amdgcn_readfirstlane(
-                (int)(bit ? t.link[node].hi : t.link[node].lo));
-            if (child == kNil) { err = kEINVAL; return -1; }
-            d++;
-            node = child;
-            if (child < (int)T::kRoot) { break; }
-            if (d >= 2 * kStack) { err = kEINVAL; return -1; }
-        }
-    }
-    // lane d' holds depth d' (0 = root, d = leaf)
-    Chain c;
-    c.mine = mine;
-    c.par = lane_below(mine);                            // lane d-1 holds the parent
-    c.gpar = lane_below(c.par);
-    c.levels = d;
-    c.holds = lane <= d;
-    c.active = lane >= 1 && lane <= d;
-    c.has_g = lane >= 2 && lane <= d;
-    t.bump_wave(node, c, lane);
+    if (r.overrun()) { err = kE2BIG; return -1; }                       // bitstream.h:74
+    if (node == (int)kNil) { err = kEINVAL; return -1; }
+    const Chain c = t.chain_up(node, lane);
+    (void)t.bump_wave(node, c, lane);
     return node;
 }
 
 __global__ __launch_bounds__(kWave)
-void decode_kernel(const uint8_t* __restrict__ in,
-                   const uint64_t* __restrict__ in_off,
-                   uint8_t* out,
-                   const uint64_t* __restrict__ out_off,
-                   int32_t* __restrict__ err_out,
-                   uint64_t* __restrict__ end_bit,   // optional: bit position after the last symbol
-                   uint32_t n_blocks,
-                   uint64_t start_bit) {
+void entropy_decode_kernel(const uint8_t* __restrict__ in,
+                           const uint64_t* __restrict__ in_off,
+                           const uint64_t* __restrict__ out_off,
+                           uint32_t* __restrict__ tokens,
+                           uint32_t* __restrict__ tok_count,
+                           int32_t* __restrict__ err_out,
+                           uint64_t* __restrict__ end_bit,   // optional: bit position after the last symbol
+                           uint32_t n_blocks,
+                           uint64_t start_bit) {
     __shared__ DecodeLds lds;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -84,92 +72,197 @@ void decode_kernel(const uint8_t* __restrict__ in,
 
     LitTree lit; PosTree pos;
     bind(lit, pos, &lds.entropy);
+    lit.lut = lds.luts.lit;
+    pos.lut = lds.luts.pos;
     lit.init_all(lane);
     pos.init_all(lane);
     __syncthreads();
 
-    uint8_t* dst = out + out_off[b];
     const uint64_t bytes = out_off[b + 1] - out_off[b];
+    uint32_t* tok = tokens + out_off[b];
 
     BitSource r;
-    r.in = in + in_off[b];
-    r.limit = in_off[b + 1] - in_off[b];
-    r.error = 0;
+    r.open(in + in_off[b], in_off[b + 1] - in_off[b], start_bit);
     int err = 0;
-    r.seek(start_bit);
-    if (r.error != 0) { err = r.error; }
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
     uint64_t i = 0;
+    uint32_t ntok = 0, tok_reg = 0;
     while (i < bytes && err == 0) {
         int s = read_symbol(r, lit, lane, err);
         if (err != 0) { break; }
         if (s == kLitNyt) {                                            // squeeze.h:512-520
             s = (int)r.get_lsb(9);
-            if (r.error != 0) { err = r.error; break; }
+            if (r.overrun()) { err = kE2BIG; break; }
             if (s == 256 || s >= kLitNyt) { err = kEINVAL; break; }
-            const int up = __builtin_amdgcn_readfirstlane((int)lit.link[s].up);
+            const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit.up_of(s));
             if (up != kNil) { err = kEINVAL; break; }
             if (!lit.insert_wave(s, lane)) { err = kE2BIG; break; }
         }
+        uint32_t word;
         if (s <= 0xFF) {
-            if (lane == 0) { dst[i] = (uint8_t)s; }
+            word = (uint32_t)s;
             i++;
-            continue;
+        } else {
+            int base, xb;                                              // squeeze.h:458-474
+            len_base_of(s - kSymLen0, base, xb);
+            int len = base;
+            if (xb != 0) {
+                len += (int)r.get_lsb(xb);
+                if (r.overrun()) { err = kE2BIG; break; }
+            }
+            if (len < kLenMin || len > kLenMax) { err = kEINVAL; break; }
+            int pk = read_symbol(r, pos, lane, err);                   // squeeze.h:476-500
+            if (err != 0) { break; }
+            if (pk == kPosNyt) {
+                pk = (int)r.get_lsb(5);
+                if (r.overrun()) { err = kE2BIG; break; }
+                if (pk >= kPosNyt) { err = kEINVAL; break; }
+                const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos.up_of(pk));
+                if (up != kNil) { err = kEINVAL; break; }
+                if (!pos.insert_wave(pk, lane)) { err = kE2BIG; break; }
+            }
+            pos_base_of(pk, base, xb);
+            int dist = base;
+            if (xb != 0) {
+                dist += (int)r.get_lsb(xb);
+                if (r.overrun()) { err = kE2BIG; break; }
+            }
+            if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; break; }
+            word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
+            i += (uint64_t)len;
         }
-        int base, xb;                                                  // squeeze.h:458-474
-        len_base_of(s - kSymLen0, base, xb);
-        int len = base;
-        if (xb != 0) {
-            len += (int)r.get_lsb(xb);
-            if (r.error != 0) { err = r.error; break; }
-        }
-        if (len < kLenMin || len > kLenMax) { err = kEINVAL; break; }
-        int pk = read_symbol(r, pos, lane, err);                       // squeeze.h:476-500
-        if (err != 0) { break; }
-        if (pk == kPosNyt) {
-            pk = (int)r.get_lsb(5);
-            if (r.error != 0) { err = r.error; break; }
-            if (pk >= kPosNyt) { err = kEINVAL; break; }
-            const int up = __builtin_amdgcn_readfirstlane((int)pos.link[pk].up);
-            if (up != kNil) { err = kEINVAL; break; }
-            if (!pos.insert_wave(pk, lane)) { err = kE2BIG; break; }
-        }
-        pos_base_of(pk, base, xb);
-        int dist = base;
-        if (xb != 0) {
-            dist += (int)r.get_lsb(xb);
-            if (r.error != 0) { err = r.error; break; }
-        }
-        if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; break; }
         if (lit.fault | pos.fault) { err = kE2BIG; break; }
-        // the source bytes were written by this wave: drain the stores, then
-        // read them back from L2 (sc1), never from a possibly stale L1 line
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint8_t* src = dst + i - (uint64_t)dist;
-        for (int k = lane; k < len; k += kWave) {
-            const int m = (dist >= len) ? k : (k % dist);
-            const uint8_t v = __hip_atomic_load(src + m, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-            dst[i + (uint64_t)k] = v;
-        }
-        i += (uint64_t)len;
+        if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
+        ntok++;
+        if ((ntok & 63u) == 0) { tok[ntok - 64 + lane] = tok_reg; }
     }
-
+    if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
     if (lane == 0) {
+        tok_count[b] = ntok;
         err_out[b] = err;
         if (end_bit != nullptr) { end_bit[b] = r.pos; }
     }
 }
 
+// ---------------------------------------------------------------------------
+constexpr int kExpRegion = 39936;            // resident output bytes (x16): 32767 back + room
+constexpr int kExpSlack  = 1024;
+
+struct ExpandLds {
+    __attribute__((aligned(16))) uint8_t buf[kExpRegion + 16];
+};
+
+__global__ __launch_bounds__(kWave)
+void lz_expand_kernel(const uint32_t* __restrict__ tokens,
+                      const uint32_t* __restrict__ tok_count,
+                      uint8_t* __restrict__ out,
+                      const uint64_t* __restrict__ out_off,
+                      uint32_t n_blocks) {
+    __shared__ ExpandLds lds;
+    uint8_t* const buf = lds.buf;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }
+
+    uint8_t* dst = out + out_off[b];
+    const uint32_t* tok = tokens + out_off[b];
+    const uint32_t count = tok_count[b];      // tokens decoded before an error are still expanded
+    const bool dst_aligned = ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+
+    uint64_t base = 0;        // stream offset of buf[0] (multiple of 16)
+    uint64_t i = 0;           // next output byte
+    uint64_t flushed = 0;     // bytes [0, flushed) are in HBM (multiple of 16 until the end)
+
+    // buf[flushed-base, upto-base) -> dst[flushed, upto)
+    auto flush_to = [&](uint64_t upto) {
+        const uint64_t n = upto - flushed;
+        const uint8_t* p = buf + (flushed - base);
+        uint8_t* q = dst + flushed;
+        uint64_t done = 0;
+        if (dst_aligned && (flushed & 15u) == 0) {
+            const uint64_t rows = n / 16;
+            for (uint64_t k = lane; k < rows; k += kWave) {
+                *reinterpret_cast<uint4*>(q + k * 16) = *reinterpret_cast<const uint4*>(p + k * 16);
+            }
+            done = rows * 16;
+        }
+        for (uint64_t k = done + lane; k < n; k += kWave) { q[k] = p[k]; }
+        flushed = upto;
+    };
+
+    for (uint32_t t0 = 0; t0 < count; ) {
+        // ---- 64 tokens: lengths, prefix sum -> output offsets ------------------
+        const uint32_t left = count - t0;
+        uint32_t word = 0, mylen = 0;
+        if ((uint32_t)lane < left) {
+            word = tok[t0 + lane];
+            mylen = (word & kTokMatch) ? ((word >> 16) & 0x1FFu) : 1u;
+        }
+        uint32_t incl = mylen;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) { incl += up; }
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        uint64_t room = (uint64_t)kExpRegion - (i - base);
+        if ((uint64_t)total > room && (i - base) > 32767 + kExpSlack) {
+            // make room: finished rows go to HBM, the last 32767 bytes stay
+            flush_to(i & ~(uint64_t)15);
+            const uint64_t new_base = (i - 32767) & ~(uint64_t)15;
+            const uint32_t shift = (uint32_t)(new_base - base);
+            const uint32_t live = (uint32_t)(i - new_base);
+            for (uint32_t off0 = 0; off0 < live; off0 += kWave * 16) {
+                const uint32_t off = off0 + (uint32_t)lane * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (off < live) { v = *reinterpret_cast<const uint4*>(buf + shift + off); }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                if (off < live) { *reinterpret_cast<uint4*>(buf + off) = v; }
+            }
+            base = new_base;
+            room = (uint64_t)kExpRegion - (i - base);
+        }
+        // the longest prefix of these tokens that fits (>= 1: room >= 257 here)
+        const uint64_t fits = __ballot((uint64_t)incl <= room && (uint32_t)lane < left);
+        const int ntake = __builtin_popcountll(fits);
+        const bool mine_in = lane < ntake;
+        const uint32_t o = (uint32_t)(i - base) + incl - mylen;  // LDS offset of my token's output
+        // ---- literals: all at once ------------------------------------------------
+        if (mine_in && (word & kTokMatch) == 0) { buf[o] = (uint8_t)word; }
+        // ---- back references: in token order, 64 lanes per copy --------------------
+        uint64_t mm = __ballot(mine_in && (word & kTokMatch) != 0);
+        while (mm != 0) {
+            const int ml = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, ml);
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)o, ml);
+            const int len = (int)((w >> 16) & 0x1FFu);
+            const int dist = (int)(w & 0x7FFFu);
+            const uint8_t* srcp = buf + at - dist;
+            if (dist >= len) {
+                for (int k = lane; k < len; k += kWave) { buf[at + k] = srcp[k]; }
+            } else {
+                for (int k = lane; k < len; k += kWave) { buf[at + k] = srcp[k % dist]; }
+            }
+        }
+        if (ntake > 0) { i += (uint32_t)__builtin_amdgcn_readlane((int)incl, ntake - 1); }
+        t0 += (uint32_t)ntake;
+    }
+    flush_to(i);
+}
+
 void launch_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
                    const uint64_t* out_off, int32_t* err, uint64_t* end_bit,
+                   uint32_t* tokens, uint32_t* tok_count,
                    uint32_t n_blocks, uint64_t start_bit, hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       in, in_off, out, out_off, err, end_bit, n_blocks, start_bit);
+    hipLaunchKernelGGL(entropy_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
+                       in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    hipLaunchKernelGGL(lz_expand_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
+                       tokens, tok_count, out, out_off, n_blocks);
 }
 
 } // namespace sqzk

@@ -7,61 +7,148 @@
 //   squeeze.h:300-315 squeeze_encode_pos       (pos tree, NYT + 5 raw bits)
 //   squeeze.h:239-246 squeeze_write_huffman    (code from the tree BEFORE the
 //                                               frequency update)
-//   squeeze.h:248-253 squeeze_flush
-// The wave runs uniformly: tokens are staged 256 at a time into LDS by all
+//   squeeze.h:248-253 squeeze_flush, bitstream.h:28-63 (MSB-first words)
+// The wave runs uniformly: tokens are staged 128 at a time into LDS by all
 // lanes; per symbol lane k takes level k of the leaf->root chain, so the
 // Huffman code is one __ballot ("am I the hi child?") and the frequency update
 // is the parallel fast path of sqz_device.h (slow path on lane 0 when the tree
-// restructures).  The bit sink state is wave-uniform; lane 0 stores the words.
+// restructures).  Codes and raw bit fields are queued as (value, width) pairs;
+// every ~60 fields the wave packs them in parallel (prefix sum of the widths,
+// LDS atomic OR into a bit image) and stores whole 8-byte words, coalesced.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
 namespace sqzk {
 
-constexpr int kTokStrip = 256;
+constexpr int kTokStrip = 128;
+constexpr int kQueue = 64;           // fields per pack
+constexpr int kQueueRoom = 8;        // a token adds at most 6 fields (+2 for a 63-bit code)
 
 struct EmitLds {
     EntropyLds entropy;
     uint32_t   strip[kTokStrip];
+    uint64_t   field[kQueue];        // value << 6 | width   (width 1..32)
+    uint64_t   image[kQueue / 2 + 2];// packed bits of one batch, stream order = MSB first
 };
 
-// huffman code of attached leaf s, read off its chain: lane k contributes the
-// branch taken at level k; ballot bit k is then bit k of the stream-order code
-template <class T>
-__device__ __forceinline__ void emit_attached(BitSink& w, T& t, int s, const Chain& c, int lane) {
-    if (c.levels < kMaxFastDepth) {
-        bool is_hi = false;
-        if (c.active) { is_hi = (t.link[c.par].hi == c.mine); }
-        const uint64_t code = __ballot(is_hi);
-        w.put_msb(code, c.levels);
-    } else {                                   // deeper than the wave is wide: serial
-        uint64_t code = 0;
-        int n = 0, a = s;
-        for (;;) {
-            const int up = __builtin_amdgcn_readfirstlane((int)t.link[a].up);
-            if (up == kNil || n >= 63) { break; }
-            const int hi = __builtin_amdgcn_readfirstlane((int)t.link[up].hi);
-            code |= (uint64_t)(hi == a ? 1 : 0) << n;
-            a = up;
-            n++;
-        }
-        w.put_msb(code, n);
-    }
-    t.bump_wave(s, c, lane);                   // squeeze.h:245: after the code is out
-}
+struct BitQueue {
+    EmitLds* lds;
+    uint8_t* out;        // global
+    uint64_t capacity;
+    uint64_t bytes;      // bytes produced so far (as the reference counts them)
+    int      count;      // queued fields
+    int      carry;      // bits already sitting in image[0] (0..63)
+    int      error;
 
-// squeeze.h:278-288 / :300-315: symbol through tree t with NYT escape
+    // value's low `width` bits, first-out bit = most significant; width 1..32
+    __device__ __forceinline__ void push32(uint32_t value, int width, int lane) {
+        if (lane == 0) { lds->field[count] = ((uint64_t)value << 6) | (uint64_t)width; }
+        count++;
+    }
+    __device__ __forceinline__ void push(uint64_t value, int width, int lane) {
+        if (width > 32) {
+            push32((uint32_t)(value >> 32), width - 32, lane);
+            push32((uint32_t)value, 32, lane);
+        } else {
+            push32((uint32_t)value, width, lane);
+        }
+    }
+    // value LSB first (squeeze_write_bits, squeeze.h:231-237), width 1..32
+    __device__ __forceinline__ void push_lsb(uint32_t value, int width, int lane) {
+        push32(__brev(value) >> (32 - width), width, lane);
+    }
+
+    // store 8-byte words [0, words) of the image (bitstream.h:33-43)
+    __device__ __forceinline__ void store_words(int words, int lane) {
+        if (error != 0 || words == 0) { return; }
+        const uint64_t room = capacity - bytes;
+        if (lane < words) {
+            const uint64_t w = lds->image[lane];
+            const uint64_t at = (uint64_t)lane * 8;
+            if (at + 8 <= room) {
+                *reinterpret_cast<uint64_t*>(out + bytes + at) = __builtin_bswap64(w);
+            } else {
+                for (int k = 0; k < 8; k++) {              // byte by byte up to the capacity
+                    if (at + (uint64_t)k < room) { out[bytes + at + k] = (uint8_t)(w >> (56 - 8 * k)); }
+                }
+            }
+        }
+        if ((uint64_t)words * 8 <= room) { bytes += (uint64_t)words * 8; }
+        else { bytes = capacity; error = kE2BIG; }
+    }
+
+    // pack the queued fields behind the carried bits, store the full words
+    __device__ __forceinline__ void pack(int lane) {
+        if (count == 0) { return; }
+        uint32_t v = 0, n = 0;
+        if (lane < count) {
+            const uint64_t f = lds->field[lane];
+            v = (uint32_t)(f >> 6);
+            n = (uint32_t)(f & 63u);
+        }
+        uint32_t incl = n;                                  // inclusive scan of the widths
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) { incl += up; }
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + (uint32_t)carry;
+        if (n != 0) {
+            const uint32_t o = (uint32_t)carry + incl - n;  // first stream bit of this field
+            const uint32_t w = o >> 6, s = o & 63u;
+            if (s + n <= 64) {
+                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+                         (unsigned long long)v << (64 - s - n));
+            } else {
+                const uint32_t r = s + n - 64;              // bits spilling into the next word
+                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+                         (unsigned long long)(v >> r));
+                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w + 1]),
+                         (unsigned long long)v << (64 - r));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int words = (int)(total >> 6);
+        store_words(words, lane);
+        const uint64_t rest = lds->image[words];           // partial word becomes the new carry
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane < kQueue / 2 + 2) { lds->image[lane] = (lane == 0) ? rest : 0ull; }
+        carry = (int)(total & 63u);
+        count = 0;
+    }
+
+    __device__ __forceinline__ void flush(int lane) {       // bitstream.h:112-114
+        pack(lane);
+        if (carry > 0) { store_words(1, lane); carry = 0; }
+    }
+};
+
+// squeeze.h:278-288 / :300-315: symbol s through tree t with the NYT escape
 template <class T>
-__device__ __forceinline__ void emit_coded(BitSink& w, T& t, int s, int nyt, int raw_bits,
+__device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, int raw_bits,
                                            int lane, int& err) {
-    const Chain c = t.chain_up(s, lane);
-    if (c.levels == 0) {                       // unseen (node[s].bits == 0)
-        const Chain cn = t.chain_up(nyt, lane);
-        emit_attached(w, t, nyt, cn, lane);
-        w.put_lsb((uint32_t)s, raw_bits);
+    Chain c = t.chain_up(s, lane);
+    const bool unseen = (c.levels == 0);                    // node[s].bits == 0
+    if (unseen) { c = t.chain_up(nyt, lane); }
+    const int leaf = unseen ? nyt : s;
+    uint64_t code = t.bump_wave(leaf, c, lane);             // code of the tree BEFORE the update
+    int width = c.levels;
+    if (width >= kMaxFastDepth) {                           // deeper than the wave is wide: serial
+        code = 0; width = 0;
+        int a = leaf;
+        for (;;) {
+            const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.up_of(a));
+            if (up == kNil || width >= 63) { break; }
+            const Node pn = unpack(uni64(t.link[up]));
+            code |= (uint64_t)(pn.hi == (uint32_t)a ? 1 : 0) << width;
+            a = (int)up;
+            width++;
+        }
+    }
+    q.push(code & ((width >= 64) ? ~0ull : ((1ull << width) - 1)), width, lane);
+    if (unseen) {
+        q.push_lsb((uint32_t)s, raw_bits, lane);
         if (!t.insert_wave(s, lane)) { err = kE2BIG; }
-    } else {
-        emit_attached(w, t, s, c, lane);
     }
 }
 
@@ -84,19 +171,23 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     bind(lit, pos, &lds.entropy);
     lit.init_all(lane);
     pos.init_all(lane);
+    if (lane < kQueue / 2 + 2) {
+        // header bits that precede the payload (single-stream API): the carry
+        lds.image[lane] = (lane == 0 && prefix_fill > 0) ? (prefix_acc << (64 - prefix_fill)) : 0ull;
+    }
     __syncthreads();
 
     const uint32_t* tok = tokens + tok_off[b];
     const uint32_t count = tok_count[b];
 
-    BitSink w;
-    w.out = out + out_off[b];
-    w.capacity = out_off[b + 1] - out_off[b];
-    w.bytes = 0;
-    w.acc = prefix_acc;
-    w.fill = prefix_fill;
-    w.error = 0;
-    w.writer = (lane == 0);
+    BitQueue q;
+    q.lds = &lds;
+    q.out = out + out_off[b];
+    q.capacity = out_off[b + 1] - out_off[b];
+    q.bytes = 0;
+    q.count = 0;
+    q.carry = prefix_fill;
+    q.error = 0;
     int err = 0;
 
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
@@ -110,26 +201,30 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         __syncthreads();
         for (uint32_t k = 0; k < take && err == 0; k++) {
             const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.strip[k]);
-            if ((t & kTokMatch) == 0) {
-                emit_coded(w, lit, (int)(t & 0xFFu), kLitNyt, 9, lane, err);
-            } else {
-                const int len = (int)((t >> 16) & 0x1FFu);
-                const int dist = (int)(t & 0x7FFFu);
-                const Code lc = len_code(len);                        // squeeze.h:290-298
-                emit_coded(w, lit, kSymLen0 + lc.code, kLitNyt, 9, lane, err);
-                if (lc.xbits > 0) { w.put_lsb((uint32_t)lc.extra, lc.xbits); }
-                const Code pc = pos_code(dist);                       // squeeze.h:300-315
-                emit_coded(w, pos, pc.code, kPosNyt, 5, lane, err);
-                if (pc.xbits > 0) { w.put_lsb((uint32_t)pc.extra, pc.xbits); }
+            const bool is_match = (t & kTokMatch) != 0;
+            Code lc = {0, 0, 0};
+            int s_lit = (int)(t & 0xFFu);
+            if (is_match) {
+                lc = len_code((int)((t >> 16) & 0x1FFu));             // squeeze.h:290-298
+                s_lit = kSymLen0 + lc.code;
             }
-            if (w.error != 0) { err = w.error; }
+            emit_coded(q, lit, s_lit, kLitNyt, 9, lane, err);
+            if (is_match) {
+                if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
+                const Code pc = pos_code((int)(t & 0x7FFFu));         // squeeze.h:300-315
+                emit_coded(q, pos, pc.code, kPosNyt, 5, lane, err);
+                if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
+            }
+            if (q.count > kQueue - kQueueRoom) { q.pack(lane); }
+            if (q.error != 0) { err = q.error; }
             if (lit.fault | pos.fault) { err = kE2BIG; }
         }
     }
 
-    if (err == 0) { w.flush(); err = w.error; }
+    if (err == 0) { q.flush(lane); err = q.error; }
+    else { q.pack(lane); }
     if (lane == 0) {
-        out_bytes[b] = w.bytes;
+        out_bytes[b] = q.bytes;
         err_out[b] = err;
     }
 }

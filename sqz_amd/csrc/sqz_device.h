@@ -140,44 +140,62 @@ struct BitSink {
     }
 };
 
-// Bit source over global memory (bitstream.h:65-93): words are big-endian,
-// bits leave from the top.  `limit` = available bytes.
+// Bit source over global memory (bitstream.h:65-93): the stream is read MSB
+// first; the reference fetches it in 8-byte big-endian groups and fails with
+// E2BIG when a group is incomplete (:72-80), so only the first limit/8*8 bytes
+// are readable.  Driven wave-uniformly: `acc` keeps the next `valid` (>= 32
+// after fill()) bits left-aligned, refilled 32 bits at a time with the following
+// dword already in flight.  Bits past the readable end read as zero and raise
+// E2BIG once they are CONSUMED (checked by the caller per symbol).
 struct BitSource {
     const uint8_t* in;
-    uint64_t limit;
-    uint64_t pos;       // absolute bit position of the next bit
+    uint64_t readable;   // bits
+    uint64_t pos;        // bits consumed
     uint64_t acc;
-    int      left;
+    int      valid;      // bits in acc
+    uint32_t ahead;      // the dword after the ones already in acc (big-endian value)
     int      error;
 
-    __device__ __forceinline__ void seek(uint64_t bitpos) {
-        pos = bitpos; left = 0; acc = 0;
-        const int skip = (int)(bitpos & 63);
-        if (skip != 0) { refill_word(bitpos >> 6); acc <<= skip; left = 64 - skip; }
-    }
-
-    __device__ __forceinline__ void refill_word(uint64_t w) {
-        const uint64_t byte = w * 8;
-        if (byte + 8 <= limit) {
-            acc = __builtin_bswap64(*reinterpret_cast<const uint64_t*>(in + byte));
-        } else {                      // bitstream.h:72-80: short tail is an error
-            error = kE2BIG;
-            acc = 0;
+    __device__ __forceinline__ uint32_t fetch(uint64_t bit_at) const {   // bit_at % 32 == 0
+        if (bit_at + 32 <= readable) {
+            return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(in + (bit_at >> 3)));
         }
-        left = 64;
+        return 0u;
     }
 
-    __device__ __forceinline__ int bit() {
-        if (error != 0) { return 0; }
-        if (left == 0) { refill_word(pos >> 6); if (error != 0) { return 0; } }
-        const int b = (int)(acc >> 63);
-        acc <<= 1; left--; pos++;
-        return b;
+    __device__ __forceinline__ void open(const uint8_t* p, uint64_t limit_bytes, uint64_t start_bit) {
+        in = p;
+        readable = (limit_bytes / 8) * 64;
+        error = 0;
+        const uint64_t w = start_bit & ~(uint64_t)31;
+        pos = start_bit;
+        acc = ((uint64_t)fetch(w) << 32) | (uint64_t)fetch(w + 32);
+        valid = 64 - (int)(start_bit - w);
+        acc <<= (start_bit - w);
+        ahead = fetch(w + 64);
     }
 
-    __device__ __forceinline__ uint32_t get_lsb(int nbits) { // bitstream.h:95-103
-        uint32_t v = 0;
-        for (int b = 0; b < nbits && error == 0; b++) { v |= (uint32_t)bit() << b; }
+    // make at least 32 bits available
+    __device__ __forceinline__ void fill() {
+        if (valid < 32) {
+            acc |= (uint64_t)ahead << (32 - valid);
+            valid += 32;
+            ahead = fetch(pos + (uint64_t)valid);        // in flight until the next fill
+        }
+    }
+
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
+
+    __device__ __forceinline__ void skip(int n) { acc <<= n; valid -= n; pos += (uint64_t)n; }
+
+    // consumed past the readable end?  (bitstream.h:74)
+    __device__ __forceinline__ bool overrun() const { return pos > readable; }
+
+    // value LSB first (bitstream.h:95-103), n = 1..16
+    __device__ __forceinline__ uint32_t get_lsb(int n) {
+        fill();
+        const uint32_t v = __brev(peek(n)) >> (32 - n);
+        skip(n);
         return v;
     }
 };
@@ -200,13 +218,34 @@ struct BitSource {
 //    the chain (every internal count is the sum of its children), which the
 //    lanes then do in one step.  Any flag -> the slow path runs instead, from
 //    the untouched state, so the result is the reference's in both cases.
-struct __attribute__((aligned(8))) Links {
-    uint16_t up, lo, hi, bits;
-};
-constexpr uint16_t kNil = 0xFFFFu;
-
-constexpr int kStack = 320;   // >= deepest possible tree (<= 286 leaves)
+//
+// A node's links are one 64-bit word: up | up2 | up3 | lo | hi (10 bits each,
+// 0x3FF = none) | depth (6 bits).  up2 / up3 (grandparent, great-grandparent)
+// exist only to shorten the leaf->root walk of the fast path to one dependent
+// LDS read per three levels; the slow path maintains them wherever it moves a
+// subtree (relabel), and never reads them.
+constexpr uint32_t kNil = 0x3FFu;
+constexpr int kStack = 128;          // deepest chain the slow path follows (fault beyond)
 constexpr int kMaxFastDepth = 60;
+
+struct Node {                        // unpacked view of a link word
+    uint32_t up, up2, up3, lo, hi, bits;
+};
+
+__device__ __forceinline__ Node unpack(uint64_t w) {
+    Node n;
+    const uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 30);
+    n.up = a & 0x3FFu; n.up2 = (a >> 10) & 0x3FFu; n.up3 = (a >> 20) & 0x3FFu;
+    n.lo = b & 0x3FFu; n.hi = (b >> 10) & 0x3FFu; n.bits = (b >> 20) & 0x3Fu;
+    return n;
+}
+
+__device__ __forceinline__ uint64_t pack(const Node& n) {
+    return (uint64_t)(n.up | (n.up2 << 10) | (n.up3 << 20)) |
+           ((uint64_t)(n.lo | (n.hi << 10) | (n.bits << 20)) << 30);
+}
+
+constexpr uint64_t kEmptyLinks = 0x3FFFFFFFull | (0xFFFFFull << 30);   // all nil, depth 0
 
 // shared per-wave scratch for both trees
 struct TreeScratch {
@@ -220,6 +259,11 @@ __device__ __forceinline__ int lane_above(int v) {          // lane k <- lane k+
 }
 __device__ __forceinline__ int lane_below(int v) {          // lane k <- lane k-1
     return __builtin_amdgcn_update_dpp((int)kNil, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
 // one lane's share of a root path: its node, that node's parent and grandparent
@@ -236,14 +280,16 @@ struct Chain {
 template <int LEAVES, int NODES, int REF_LEAVES>
 struct Tree {
     // LDS storage
-    Links*    link;
+    uint64_t* link;
     uint32_t* freq;
     TreeScratch* scratch;
+    uint16_t* lut;      // decoder only: 256 entries, node | bits used << 10
     // wave-uniform registers
     int next;           // next free internal id
     int depth;          // huffman.h:26 high-water mark
     int complete;       // huffman.h:27
-    int fault;          // stack overflow guard (never set for valid alphabets)
+    int fault;          // stack / depth guard (never set for realistic streams)
+    int lut_ok;         // decoder: the lookup table matches the tree
 
     static constexpr int kRoot = LEAVES;
     static constexpr int kIdEnd =
@@ -252,15 +298,15 @@ struct Tree {
     // all lanes: clear storage (huffman.h:251-269)
     __device__ __forceinline__ void init_all(int lane) {
         for (int i = lane; i < NODES; i += kWave) {
-            link[i] = Links{kNil, kNil, kNil, 0};
+            link[i] = kEmptyLinks;
             freq[i] = 0;
         }
-        next = kRoot + 1; depth = 0; complete = 0; fault = 0;
+        next = kRoot + 1; depth = 0; complete = 0; fault = 0; lut_ok = 0;
     }
 
-    __device__ __forceinline__ Links ld(int i) const {
-        return link[i];    // 8-byte aligned aggregate: one ds_read_b64
-    }
+    __device__ __forceinline__ Node ld(int i) const { return unpack(link[i]); }
+    __device__ __forceinline__ void st(int i, const Node& n) { link[i] = pack(n); }
+    __device__ __forceinline__ uint32_t up_of(int i) const { return (uint32_t)link[i] & 0x3FFu; }
 
     // after a lane-0 section: make the registers uniform again
     __device__ __forceinline__ void sync_regs() {
@@ -271,26 +317,30 @@ struct Tree {
     }
 
     // ---------------- slow path: the reference sequence, one lane -----------
-    // huffman.h:41-62 (depths only: codes are read off the chain when needed)
+    // huffman.h:41-62 (depths; codes are read off the chain when needed).  Also
+    // refreshes up2/up3 of everything below `top`.
     __device__ __forceinline__ void relabel(int top) {
         if (top == kRoot) { depth = 0; }
         int sp = 0;
         scratch->walk[sp++] = (uint16_t)top;
         while (sp > 0) {
             const int v = scratch->walk[--sp];
-            const Links n = ld(v);
-            const int b = n.bits;
+            const Node n = ld(v);
+            const int b = (int)n.bits;
             if (b > depth) { depth = b; }
-            if (n.hi != kNil) {
-                link[n.hi].bits = (uint16_t)(b + 1);
-                if (n.hi >= LEAVES) {
-                    if (sp < kStack) { scratch->walk[sp++] = n.hi; } else { fault = 1; }
-                } else if (b + 1 > depth) { depth = b + 1; }
-            }
-            if (n.lo != kNil) {
-                link[n.lo].bits = (uint16_t)(b + 1);
-                if (n.lo >= LEAVES) {
-                    if (sp < kStack) { scratch->walk[sp++] = n.lo; } else { fault = 1; }
+            if (b >= 63) { fault = 1; continue; }             // reference asserts bits < 63
+            const uint32_t kids[2] = { n.hi, n.lo };
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t ch = kids[j];
+                if (ch == kNil) { continue; }
+                Node c = ld((int)ch);
+                c.bits = (uint32_t)(b + 1);
+                c.up2 = n.up;
+                c.up3 = n.up2;
+                st((int)ch, c);
+                if (ch >= (uint32_t)LEAVES) {
+                    if (sp < kStack) { scratch->walk[sp++] = (uint16_t)ch; } else { fault = 1; }
                 } else if (b + 1 > depth) { depth = b + 1; }
             }
         }
@@ -298,7 +348,7 @@ struct Tree {
 
     // huffman.h:90-96
     __device__ __forceinline__ void sum(int i) {
-        const Links n = ld(i);
+        const Node n = ld(i);
         const uint32_t a = n.lo != kNil ? freq[n.lo] : 0u;
         const uint32_t b = n.hi != kNil ? freq[n.hi] : 0u;
         freq[i] = a + b;
@@ -306,14 +356,15 @@ struct Tree {
 
     // huffman.h:64-86
     __device__ __forceinline__ int order_pair(int i) {
-        const int p = link[i].up;
+        const uint32_t p = up_of(i);
         if (p == kNil) { return i; }
-        const Links n = ld(p);
+        Node n = ld((int)p);
         if (n.lo != kNil && n.hi != kNil && freq[n.lo] > freq[n.hi]) {
-            link[p].lo = n.hi;
-            link[p].hi = n.lo;
-            relabel(p);
-            return i == n.lo ? n.hi : n.lo;
+            const uint32_t l = n.lo, r = n.hi;
+            n.lo = r; n.hi = l;
+            st((int)p, n);
+            relabel((int)p);
+            return i == (int)l ? (int)r : (int)l;
         }
         return i;
     }
@@ -322,13 +373,13 @@ struct Tree {
     // sibling order up to the root, remembering (parent, child) per level
     __device__ __forceinline__ int climb(int i, int sp) {
         for (;;) {
-            const int p = link[i].up;
+            const uint32_t p = up_of(i);
             if (p == kNil) { sum(i); break; }
-            sum(p);
+            sum((int)p);
             i = order_pair(i);
-            if (sp < kStack) { scratch->pend[sp++] = ((uint32_t)p << 16) | (uint32_t)i; }
+            if (sp < kStack) { scratch->pend[sp++] = (p << 16) | (uint32_t)i; }
             else { fault = 1; }
-            i = p;
+            i = (int)p;
         }
         return sp;
     }
@@ -340,18 +391,25 @@ struct Tree {
         while (sp > 0) {
             const uint32_t e = scratch->pend[--sp];
             const int p = (int)(e >> 16), c = (int)(e & 0xFFFFu);
-            const Links np = ld(p);
-            if (np.up == kNil || np.hi != c) { continue; }          // :143
-            const int par = link[c].up;
-            const int g = link[par].up;
-            const Links ng = ld(g);
-            const bool par_is_left = (ng.lo == par);
-            const int uncle = par_is_left ? ng.hi : ng.lo;
+            const Node np = ld(p);
+            if (np.up == kNil || np.hi != (uint32_t)c) { continue; }    // :143
+            const int par = (int)up_of(c);
+            const int g = (int)up_of(par);
+            Node ng = ld(g);
+            const bool par_is_left = (ng.lo == (uint32_t)par);
+            const int uncle = (int)(par_is_left ? ng.hi : ng.lo);
             if (!(freq[c] > freq[uncle])) { continue; }              // :108
-            link[c].up = (uint16_t)g;
-            if (par_is_left) { link[g].hi = (uint16_t)c; } else { link[g].lo = (uint16_t)c; }
-            link[par].hi = (uint16_t)uncle;
-            link[uncle].up = (uint16_t)par;
+            Node nc = ld(c);
+            nc.up = (uint32_t)g;
+            st(c, nc);
+            if (par_is_left) { ng.hi = (uint32_t)c; } else { ng.lo = (uint32_t)c; }
+            st(g, ng);
+            Node npar = ld(par);
+            npar.hi = (uint32_t)uncle;
+            st(par, npar);
+            Node nu = ld(uncle);
+            nu.up = (uint32_t)par;
+            st(uncle, nu);
             sum(par);
             sum(g);
             (void)order_pair(c);
@@ -368,10 +426,16 @@ struct Tree {
         int at = kRoot;
         freq[i] = 1;
         while (at >= LEAVES) {                                        // :156-170
-            const Links n = ld(at);
-            if (n.hi == kNil) { link[at].hi = (uint16_t)i; link[i].up = (uint16_t)at; break; }
-            if (n.lo == kNil) { link[at].lo = (uint16_t)i; link[i].up = (uint16_t)at; break; }
-            at = n.lo;
+            Node n = ld(at);
+            if (n.hi == kNil || n.lo == kNil) {
+                if (n.hi == kNil) { n.hi = (uint32_t)i; } else { n.lo = (uint32_t)i; }
+                st(at, n);
+                Node ni = ld(i);
+                ni.up = (uint32_t)at;
+                st(i, ni);
+                break;
+            }
+            at = (int)n.lo;
         }
         if (at >= LEAVES) {                                           // :171-173
             freq[at] += 1;
@@ -381,17 +445,24 @@ struct Tree {
             complete = 1;
         } else {                                                      // :184-209
             const int fresh = next++;
-            const Links na = ld(at);
-            link[fresh] = Links{na.up, (uint16_t)at, (uint16_t)i, na.bits};
+            Node na = ld(at);
+            Node nf = na;                     // takes at's place: same up/up2/up3/depth
+            nf.lo = (uint32_t)at; nf.hi = (uint32_t)i;
+            st(fresh, nf);
             freq[fresh] = freq[at];
             if (na.up != kNil) {
-                if (link[na.up].lo == at) { link[na.up].lo = (uint16_t)fresh; }
-                else                      { link[na.up].hi = (uint16_t)fresh; }
+                Node nabove = ld((int)na.up);
+                if (nabove.lo == (uint32_t)at) { nabove.lo = (uint32_t)fresh; }
+                else                            { nabove.hi = (uint32_t)fresh; }
+                st((int)na.up, nabove);
             }
-            link[at].up = (uint16_t)fresh;
-            link[at].bits = (uint16_t)(na.bits + 1);
-            link[i].up = (uint16_t)fresh;
-            link[i].bits = (uint16_t)(na.bits + 1);
+            na.up = (uint32_t)fresh;
+            na.bits = na.bits + 1;
+            st(at, na);
+            Node ni = ld(i);
+            ni.up = (uint32_t)fresh;
+            ni.bits = nf.bits + 1;
+            st(i, ni);
             sum(fresh);
             at = fresh;
         }
@@ -405,20 +476,56 @@ struct Tree {
         int ok = 1;
         if (lane == 0) { ok = insert(i) ? 1 : 0; }
         sync_regs();
+        lut_ok = 0;
         return __builtin_amdgcn_readfirstlane(ok) != 0;
     }
 
+    __device__ __forceinline__ void changed_wave(int s, int lane) {
+        if (lane == 0) { freq[s] += 1; changed(s); }
+        sync_regs();
+        lut_ok = 0;
+    }
+
+    // decoder: table over the next 8 stream bits -> (node reached, bits used).
+    // Entry = node | used << 10; a missing child gives node = kNil.
+    __device__ __forceinline__ void build_lut(int lane) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = lane + 64 * j;
+            int node = kRoot, used = 0;
+            for (int level = 0; level < 8; level++) {
+                const uint32_t kids = (uint32_t)(link[node] >> 30);
+                const int bit = (idx >> (7 - level)) & 1;
+                const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
+                used = level + 1;
+                node = child;
+                if (child == (int)kNil || child < LEAVES) { break; }
+            }
+            lut[idx] = (uint16_t)(node | (used << 10));
+        }
+        lut_ok = 1;
+    }
+
     // ---------------- fast path ------------------------------------------------
-    // leaf -> root walk; lane k receives level k (0 = the leaf).  Uniform.
+    // leaf -> root walk, three levels per dependent LDS read; lane k receives
+    // level k (0 = the leaf).  Uniform control flow.
     __device__ __forceinline__ Chain chain_up(int s, int lane) const {
-        int mine = kNil;
+        int mine = (lane == 0) ? s : (int)kNil;
         int a = s, k = 0;
         for (;;) {
-            mine = (lane == k) ? a : mine;
-            const int up = __builtin_amdgcn_readfirstlane((int)link[a].up);
-            if (up == kNil || k >= kMaxFastDepth) { break; }
-            a = up;
-            k++;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)link[a]);
+            const uint32_t u1 = w & 0x3FFu, u2 = (w >> 10) & 0x3FFu, u3 = (w >> 20) & 0x3FFu;
+            if (u1 == kNil) { break; }
+            // lanes k+1..k+3 take up / up2 / up3 (a nil stays nil)
+            const int f = lane - k;
+            const bool take = (f >= 1 && f <= 3);
+            const uint32_t pick = (w >> (take ? 10 * (f - 1) : 0)) & 0x3FFu;
+            mine = take ? (int)pick : mine;
+            if (u2 == kNil) { k += 1; break; }
+            if (u3 == kNil) { k += 2; break; }
+            k += 3;
+            a = (int)u3;
+            if (a == kRoot || k >= kMaxFastDepth) { break; }
         }
         Chain c;
         c.mine = mine;
@@ -431,36 +538,36 @@ struct Tree {
         return c;
     }
 
-    // huffman_inc_frequency for an ATTACHED leaf s whose chain is `c`
-    __device__ __forceinline__ void bump_wave(int s, const Chain& c, int lane) {
-        if (complete != 0 || depth >= 63) { complete = 1; return; }   // huffman.h:228-234
+    // huffman_inc_frequency for an ATTACHED leaf s whose chain is `c`.
+    // Returns the ballot of "my node is the hi child" (the stream-order code).
+    __device__ __forceinline__ uint64_t bump_wave(int s, const Chain& c, int lane) {
+        // stage A: my count, my parent's and my grandparent's links
+        const int i_mine = c.holds ? c.mine : kRoot;
+        const int i_par = c.active ? c.par : kRoot;
+        const int i_gpar = c.has_g ? c.gpar : kRoot;
+        const uint32_t fc = freq[i_mine];
+        const Node lp = ld(i_par);
+        const Node lg = ld(i_gpar);
+        const bool is_hi = c.active && (lp.hi == (uint32_t)c.mine);
+        const uint64_t code = __ballot(is_hi);
+        if (complete != 0 || depth >= 63) { complete = 1; return code; }   // huffman.h:228-234
+        // stage B: sibling and uncle counts
+        const uint32_t sib = is_hi ? lp.lo : lp.hi;
+        const uint32_t uncle = (lg.lo == (uint32_t)c.par) ? lg.hi : lg.lo;
+        const bool has_sib = c.active && sib != kNil;
+        const bool has_unc = is_hi && c.has_g && uncle != kNil;
+        const uint32_t fs = freq[has_sib ? (int)sib : kRoot];
+        const uint32_t fu = freq[has_unc ? (int)uncle : kRoot];
         bool flag = false;
-        uint32_t fc = 0;
-        if (c.levels < kMaxFastDepth) {
-            if (c.holds) { fc = freq[c.mine]; }
-            if (c.active) {
-                const Links lp = ld(c.par);
-                const bool is_hi = (lp.hi == c.mine);
-                const int sib = is_hi ? lp.lo : lp.hi;
-                if (sib != kNil) {
-                    const uint32_t fs = freq[sib];
-                    flag = is_hi ? (fs > fc + 1) : (fc + 1 > fs);
-                }
-                if (is_hi && c.has_g) {
-                    const Links lg = ld(c.gpar);
-                    const int uncle = (lg.lo == c.par) ? lg.hi : lg.lo;
-                    flag = flag || (fc + 1 > freq[uncle]);
-                }
-            }
-        } else {
-            flag = true;                                              // too deep: slow path
-        }
+        if (has_sib) { flag = is_hi ? (fs > fc + 1) : (fc + 1 > fs); }
+        if (has_unc) { flag = flag || (fc + 1 > fu); }
+        if (c.levels >= kMaxFastDepth) { flag = true; }               // too deep: slow path
         if (__ballot(flag) == 0) {
             if (c.holds) { freq[c.mine] = fc + 1; }
         } else {
-            if (lane == 0) { freq[s] += 1; changed(s); }
-            sync_regs();
+            changed_wave(s, lane);
         }
+        return code;
     }
 };
 
@@ -473,17 +580,22 @@ using LitTree = Tree<kLitLeaves, kLitNodes, 512>;
 using PosTree = Tree<kPosLeaves, kPosNodes, 32>;
 
 // LDS image of one stream's entropy state
+struct DecodeLuts {
+    uint16_t lit[256];
+    uint16_t pos[256];
+};
+
 struct EntropyLds {
-    Links    lit_link[kLitNodes];
-    Links    pos_link[kPosNodes];
+    uint64_t lit_link[kLitNodes];
+    uint64_t pos_link[kPosNodes];
     uint32_t lit_freq[kLitNodes];
     uint32_t pos_freq[kPosNodes];
     TreeScratch scratch;
 };
 
 __device__ __forceinline__ void bind(LitTree& lit, PosTree& pos, EntropyLds* s) {
-    lit.link = s->lit_link; lit.freq = s->lit_freq; lit.scratch = &s->scratch;
-    pos.link = s->pos_link; pos.freq = s->pos_freq; pos.scratch = &s->scratch;
+    lit.link = s->lit_link; lit.freq = s->lit_freq; lit.scratch = &s->scratch; lit.lut = nullptr;
+    pos.link = s->pos_link; pos.freq = s->pos_freq; pos.scratch = &s->scratch; pos.lut = nullptr;
 }
 
 } // namespace sqzk

@@ -30,9 +30,11 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          int32_t* err, uint32_t n_blocks,
                          uint64_t prefix_acc, int prefix_fill, hipStream_t stream);
 
-// decode (squeeze.h:502-551)
+// decode (squeeze.h:502-551): entropy stage -> token words -> LZ77 expansion.
+// tokens: one uint32 slot per OUTPUT byte, addressed by out_off; tok_count[n].
 void launch_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
                    const uint64_t* out_off, int32_t* err, uint64_t* end_bit,
+                   uint32_t* tokens, uint32_t* tok_count,
                    uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
 
 } // namespace sqzk
