@@ -64,7 +64,8 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
                        const uint64_t* __restrict__ in_off,
                        uint32_t n_blocks,
                        uint32_t* __restrict__ buf_a,      // result lands here
-                       uint32_t* __restrict__ buf_b) {
+                       uint32_t* __restrict__ buf_b,
+                       uint32_t* __restrict__ tmp) {      // 4 bytes per position of scratch
     __shared__ SortLds lds;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
@@ -78,6 +79,10 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
     const uint32_t count = (uint32_t)(bytes - 2);             // positions with a 3-byte prefix
     uint32_t* const pa = buf_a + in_off[b];
     uint32_t* const pb = buf_b + in_off[b];
+    uint16_t* const cache = reinterpret_cast<uint16_t*>(tmp + in_off[b]);   // bytes p, p+1 per row
+    // blocks up to 16 MB carry byte 0 of the key in the element's top 8 bits from
+    // pass 1 to pass 2, so only pass 1 gathers at random
+    const bool carry = bytes <= (1u << 24);
 
     // each wave owns a contiguous slice (keeps the scatter stable without
     // workgroup barriers inside the sweep)
@@ -92,18 +97,37 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
         const int byte_ix = 2 - pass;
 
         for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
-        // ---- count ----------------------------------------------------------
-        for (uint32_t e = lo; e < hi; e += kWave) {
-            const uint32_t k = e + (uint32_t)lane;
-            const bool valid = k < hi;
-            uint32_t pos = 0, digit = 0;
-            if (valid) {
-                pos = pass == 0 ? k : from[k];
-                digit = src[pos + byte_ix];
+        // ---- count (4 rows of 64 per trip: the dependent global loads overlap) ----
+        for (uint32_t e = lo; e < hi; e += 4 * kWave) {
+            uint32_t pos[4], digit[4];
+            bool valid[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k = e + (uint32_t)(j * kWave + lane);
+                valid[j] = k < hi;
+                pos[j] = valid[j] ? (pass == 0 ? k : from[k]) : 0u;
             }
-            const uint64_t peers = peers_of(digit, valid);
-            if (valid && lanes_below(peers) == 0) {
-                lds.cnt[wave][digit] += (uint32_t)__builtin_popcountll(peers);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k = e + (uint32_t)(j * kWave + lane);
+                digit[j] = 0;
+                if (valid[j]) {
+                    if (pass == 0) { digit[j] = src[pos[j] + 2]; }
+                    else if (pass == 1) {          // the one random gather: bytes p and p+1
+                        const uint32_t w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
+                        cache[k] = (uint16_t)w;
+                        digit[j] = w >> 8;
+                    } else {
+                        digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t peers = peers_of(digit[j], valid[j]);
+                if (valid[j] && lanes_below(peers) == 0) {
+                    lds.cnt[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
+                }
             }
         }
         __syncthreads();
@@ -135,23 +159,43 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
         __syncthreads();
         for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] += lds.total[d]; }
         // ---- stable scatter (wave-private counters: no barrier needed) -------
-        for (uint32_t e = lo; e < hi; e += kWave) {
-            const uint32_t k = e + (uint32_t)lane;
-            const bool valid = k < hi;
-            uint32_t pos = 0, digit = 0;
-            if (valid) {
-                pos = pass == 0 ? k : from[k];
-                digit = src[pos + byte_ix];
+        for (uint32_t e = lo; e < hi; e += 4 * kWave) {
+            uint32_t pos[4], digit[4], elem[4];
+            bool valid[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k = e + (uint32_t)(j * kWave + lane);
+                valid[j] = k < hi;
+                pos[j] = valid[j] ? (pass == 0 ? k : from[k]) : 0u;
             }
-            const uint64_t peers = peers_of(digit, valid);
-            const uint32_t rank = lanes_below(peers);
-            uint32_t dest = 0;
-            if (valid) { dest = lds.cnt[wave][digit] + rank; }
-            __builtin_amdgcn_wave_barrier();               // all reads before the leaders' writes
-            if (valid && rank == 0) {
-                lds.cnt[wave][digit] += (uint32_t)__builtin_popcountll(peers);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k = e + (uint32_t)(j * kWave + lane);
+                digit[j] = 0; elem[j] = pos[j];
+                if (valid[j]) {
+                    if (pass == 0) { digit[j] = src[pos[j] + 2]; }
+                    else if (pass == 1) {
+                        const uint32_t w = cache[k];           // written by this lane in the count sweep
+                        digit[j] = w >> 8;
+                        if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
+                    } else {
+                        digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
+                        if (carry) { elem[j] = pos[j] & 0x00FFFFFFu; }
+                    }
+                }
             }
-            if (valid) { to[dest] = pos; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {                      // rows in order: stability
+                const uint64_t peers = peers_of(digit[j], valid[j]);
+                const uint32_t rank = lanes_below(peers);
+                uint32_t dest = 0;
+                if (valid[j]) { dest = lds.cnt[wave][digit[j]] + rank; }
+                __builtin_amdgcn_wave_barrier();               // all reads before the leaders' writes
+                if (valid[j] && rank == 0) {
+                    lds.cnt[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
+                }
+                if (valid[j]) { to[dest] = elem[j]; }
+            }
         }
         // the next pass reads what other waves of this workgroup wrote
         __threadfence_block();
@@ -180,13 +224,15 @@ void index_match_kernel(const uint8_t* __restrict__ in,
         const uint32_t i = S[r];
         const uint32_t cap = (n - i) < (uint32_t)kLenMax ? (n - i) : (uint32_t)kLenMax;
         const uint32_t reach = i < window - 1 ? i : window - 1;
-        const uint32_t key = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16);
+        // i <= n-3; a 4-byte load may touch byte i+3 == n only for the last position
+        const uint32_t key = (i + 4 <= n) ? (load_u32_unaligned(src + i) & 0x00FFFFFFu)
+            : ((uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16));
         uint32_t best = 0, dist = 0;
         for (uint32_t q = r; q > 0 && best < cap; ) {
             q--;
             const uint32_t p = S[q];                       // p < i inside a run
             if (i - p > reach) { break; }                  // everything further is farther
-            const uint32_t pk = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+            const uint32_t pk = load_u32_unaligned(src + p) & 0x00FFFFFFu;   // p < i: p+4 <= n
             if (pk != key) { break; }                      // left the run
             if (best >= (uint32_t)kLenMin && src[p + best] != src[i + best]) { continue; }
             uint32_t k = 3;
@@ -271,7 +317,7 @@ void launch_lz77_index(const uint8_t* in, const uint64_t* in_off, uint32_t n_blo
                        hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(index_sort_kernel, dim3(n_blocks), dim3(kSortThreads), 0, stream,
-                       in, in_off, n_blocks, buf_a, buf_b);
+                       in, in_off, n_blocks, buf_a, buf_b, match /* scratch until index_match */);
     if (match_groups < 1) { match_groups = 1; }
     if (match_groups > 65535) { match_groups = 65535; }
     hipLaunchKernelGGL(index_match_kernel, dim3(n_blocks, match_groups), dim3(256), 0, stream,
