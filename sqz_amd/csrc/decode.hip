@@ -78,11 +78,13 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     pos.init_all(lane);
     __syncthreads();
 
-    const uint64_t bytes = out_off[b + 1] - out_off[b];
-    uint32_t* tok = tokens + out_off[b];
+    const uint64_t o0 = uni64(out_off[b]), o1 = uni64(out_off[b + 1]);
+    const uint64_t bytes = o1 - o0;
+    uint32_t* tok = tokens + o0;
 
     BitSource r;
-    r.open(in + in_off[b], in_off[b + 1] - in_off[b], start_bit);
+    const uint64_t i0 = uni64(in_off[b]), i1 = uni64(in_off[b + 1]);
+    r.open(in + i0, i1 - i0, start_bit);
     int err = 0;
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }

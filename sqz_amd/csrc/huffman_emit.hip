@@ -27,7 +27,7 @@ constexpr int kQueueRoom = 8;        // a token adds at most 6 fields (+2 for a 
 struct EmitLds {
     EntropyLds entropy;
     uint32_t   strip[kTokStrip];
-    uint64_t   field[kQueue];        // value << 6 | width   (width 1..32)
+    uint64_t   field[kQueue];        // width << 32 | value   (width 1..32)
     uint64_t   image[kQueue / 2 + 2];// packed bits of one batch, stream order = MSB first
 };
 
@@ -42,7 +42,7 @@ struct BitQueue {
 
     // value's low `width` bits, first-out bit = most significant; width 1..32
     __device__ __forceinline__ void push32(uint32_t value, int width, int lane) {
-        if (lane == 0) { lds->field[count] = ((uint64_t)value << 6) | (uint64_t)width; }
+        if (lane == 0) { lds->field[count] = ((uint64_t)(uint32_t)width << 32) | (uint64_t)value; }
         count++;
     }
     __device__ __forceinline__ void push(uint64_t value, int width, int lane) {
@@ -83,8 +83,8 @@ struct BitQueue {
         uint32_t v = 0, n = 0;
         if (lane < count) {
             const uint64_t f = lds->field[lane];
-            v = (uint32_t)(f >> 6);
-            n = (uint32_t)(f & 63u);
+            v = (uint32_t)f;
+            n = (uint32_t)(f >> 32);
         }
         uint32_t incl = n;                                  // inclusive scan of the widths
 #pragma unroll
@@ -123,6 +123,22 @@ struct BitQueue {
     }
 };
 
+// code of a leaf deeper than the wave is wide (never seen in practice): serial walk
+__device__ __noinline__ uint64_t deep_code(const uint64_t* link, int leaf, int& width) {
+    uint64_t code = 0;
+    int n = 0, a = leaf;
+    for (;;) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)link[a] & 0x3FFu));
+        if (up == kNil || n >= 63) { break; }
+        const Node pn = unpack(uni64(link[up]));
+        code |= (uint64_t)(pn.hi == (uint32_t)a ? 1 : 0) << n;
+        a = (int)up;
+        n++;
+    }
+    width = n;
+    return code;
+}
+
 // squeeze.h:278-288 / :300-315: symbol s through tree t with the NYT escape
 template <class T>
 __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, int raw_bits,
@@ -132,20 +148,9 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
     if (unseen) { c = t.chain_up(nyt, lane); }
     const int leaf = unseen ? nyt : s;
     uint64_t code = t.bump_wave(leaf, c, lane);             // code of the tree BEFORE the update
-    int width = c.levels;
-    if (width >= kMaxFastDepth) {                           // deeper than the wave is wide: serial
-        code = 0; width = 0;
-        int a = leaf;
-        for (;;) {
-            const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.up_of(a));
-            if (up == kNil || width >= 63) { break; }
-            const Node pn = unpack(uni64(t.link[up]));
-            code |= (uint64_t)(pn.hi == (uint32_t)a ? 1 : 0) << width;
-            a = (int)up;
-            width++;
-        }
-    }
-    q.push(code & ((width >= 64) ? ~0ull : ((1ull << width) - 1)), width, lane);
+    int width = c.levels;                                   // ballot bits beyond `levels` are 0
+    if (width >= kMaxFastDepth) { code = deep_code(t.link, leaf, width); }
+    q.push(code, width, lane);
     if (unseen) {
         q.push_lsb((uint32_t)s, raw_bits, lane);
         if (!t.insert_wave(s, lane)) { err = kE2BIG; }
@@ -177,13 +182,14 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     }
     __syncthreads();
 
-    const uint32_t* tok = tokens + tok_off[b];
-    const uint32_t count = tok_count[b];
+    const uint32_t* tok = tokens + uni64(tok_off[b]);
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
 
     BitQueue q;
     q.lds = &lds;
-    q.out = out + out_off[b];
-    q.capacity = out_off[b + 1] - out_off[b];
+    const uint64_t o0 = uni64(out_off[b]), o1 = uni64(out_off[b + 1]);
+    q.out = out + o0;
+    q.capacity = o1 - o0;
     q.bytes = 0;
     q.count = 0;
     q.carry = prefix_fill;

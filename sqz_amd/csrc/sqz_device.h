@@ -153,14 +153,19 @@ struct BitSource {
     uint64_t pos;        // bits consumed
     uint64_t acc;
     int      valid;      // bits in acc
-    uint32_t ahead;      // the dword after the ones already in acc (big-endian value)
+    uint32_t ahead;      // the dword after the ones already in acc (raw, as loaded)
     int      error;
 
-    __device__ __forceinline__ uint32_t fetch(uint64_t bit_at) const {   // bit_at % 32 == 0
+    // raw little-endian dword at stream bit `bit_at` (multiple of 32); zero past the end.
+    // Kept raw so that nothing waits for the load before the next fill() needs it.
+    __device__ __forceinline__ uint32_t fetch_raw(uint64_t bit_at) const {
         if (bit_at + 32 <= readable) {
-            return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(in + (bit_at >> 3)));
+            return *reinterpret_cast<const uint32_t*>(in + (bit_at >> 3));
         }
         return 0u;
+    }
+    __device__ __forceinline__ static uint32_t be(uint32_t raw) {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bswap32(raw));
     }
 
     __device__ __forceinline__ void open(const uint8_t* p, uint64_t limit_bytes, uint64_t start_bit) {
@@ -169,18 +174,18 @@ struct BitSource {
         error = 0;
         const uint64_t w = start_bit & ~(uint64_t)31;
         pos = start_bit;
-        acc = ((uint64_t)fetch(w) << 32) | (uint64_t)fetch(w + 32);
+        acc = ((uint64_t)be(fetch_raw(w)) << 32) | (uint64_t)be(fetch_raw(w + 32));
         valid = 64 - (int)(start_bit - w);
         acc <<= (start_bit - w);
-        ahead = fetch(w + 64);
+        ahead = fetch_raw(w + 64);
     }
 
     // make at least 32 bits available
     __device__ __forceinline__ void fill() {
         if (valid < 32) {
-            acc |= (uint64_t)ahead << (32 - valid);
+            acc |= (uint64_t)be(ahead) << (32 - valid);
             valid += 32;
-            ahead = fetch(pos + (uint64_t)valid);        // in flight until the next fill
+            ahead = fetch_raw(pos + (uint64_t)valid);    // in flight until the next fill
         }
     }
 
@@ -275,6 +280,19 @@ struct Chain {
     bool has_g;        // ... and that parent is not the root
 };
 
+// The slow path lives in real (non-inlined) functions so that the per-symbol loop
+// of the kernels stays a few hundred instructions: it is taken for ~1 % of the
+// symbols, and inlining it at every call site made the kernels ~50 KB of code.
+// State crosses the call as plain values: LDS pointers + the packed registers.
+template <class T>
+__device__ __noinline__ uint32_t slow_insert(uint64_t* link, uint32_t* freq, TreeScratch* scratch,
+                                             uint32_t regs, int sym, int lane);
+template <class T>
+__device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, TreeScratch* scratch,
+                                              uint32_t regs, int sym, int lane);
+template <class T>
+__device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut, int lane);
+
 // REF_LEAVES is the reference's leaf count n (512 / 32, squeeze.h:204-205): it
 // only fixes how many leaf splits huffman_insert allows (n - 2, huffman.h:180).
 template <int LEAVES, int NODES, int REF_LEAVES>
@@ -307,6 +325,16 @@ struct Tree {
     __device__ __forceinline__ Node ld(int i) const { return unpack(link[i]); }
     __device__ __forceinline__ void st(int i, const Node& n) { link[i] = pack(n); }
     __device__ __forceinline__ uint32_t up_of(int i) const { return (uint32_t)link[i] & 0x3FFu; }
+
+    // registers <-> one word (next:10 | depth:8 | complete:1 | fault:1 | ok:1 at bit 31)
+    __device__ __forceinline__ uint32_t pack_regs() const {
+        return (uint32_t)next | ((uint32_t)(depth & 0xFF) << 10) | ((uint32_t)(complete & 1) << 18) |
+               ((uint32_t)(fault & 1) << 19);
+    }
+    __device__ __forceinline__ void unpack_regs(uint32_t r) {
+        next = (int)(r & 0x3FFu); depth = (int)((r >> 10) & 0xFFu);
+        complete = (int)((r >> 18) & 1u); fault = (int)((r >> 19) & 1u);
+    }
 
     // after a lane-0 section: make the registers uniform again
     __device__ __forceinline__ void sync_regs() {
@@ -473,36 +501,21 @@ struct Tree {
 
     // whole wave: insert through lane 0 (unseen symbols are rare: <= 286 per stream)
     __device__ __forceinline__ bool insert_wave(int i, int lane) {
-        int ok = 1;
-        if (lane == 0) { ok = insert(i) ? 1 : 0; }
-        sync_regs();
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)slow_insert<Tree>(link, freq, scratch, pack_regs(), i, lane));
+        unpack_regs(r);
         lut_ok = 0;
-        return __builtin_amdgcn_readfirstlane(ok) != 0;
+        return (r >> 31) != 0;
     }
 
     __device__ __forceinline__ void changed_wave(int s, int lane) {
-        if (lane == 0) { freq[s] += 1; changed(s); }
-        sync_regs();
+        unpack_regs((uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)slow_changed<Tree>(link, freq, scratch, pack_regs(), s, lane)));
         lut_ok = 0;
     }
 
-    // decoder: table over the next 8 stream bits -> (node reached, bits used).
-    // Entry = node | used << 10; a missing child gives node = kNil.
     __device__ __forceinline__ void build_lut(int lane) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int idx = lane + 64 * j;
-            int node = kRoot, used = 0;
-            for (int level = 0; level < 8; level++) {
-                const uint32_t kids = (uint32_t)(link[node] >> 30);
-                const int bit = (idx >> (7 - level)) & 1;
-                const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
-                used = level + 1;
-                node = child;
-                if (child == (int)kNil || child < LEAVES) { break; }
-            }
-            lut[idx] = (uint16_t)(node | (used << 10));
-        }
+        slow_build_lut<Tree>(link, lut, lane);
         lut_ok = 1;
     }
 
@@ -513,7 +526,9 @@ struct Tree {
         int mine = (lane == 0) ? s : (int)kNil;
         int a = s, k = 0;
         for (;;) {
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)link[a]);
+            // low half of the word: up | up2 | up3
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)reinterpret_cast<const uint32_t*>(link)[2 * a]);
             const uint32_t u1 = w & 0x3FFu, u2 = (w >> 10) & 0x3FFu, u3 = (w >> 20) & 0x3FFu;
             if (u1 == kNil) { break; }
             // lanes k+1..k+3 take up / up2 / up3 (a nil stays nil)
@@ -551,17 +566,18 @@ struct Tree {
         const bool is_hi = c.active && (lp.hi == (uint32_t)c.mine);
         const uint64_t code = __ballot(is_hi);
         if (complete != 0 || depth >= 63) { complete = 1; return code; }   // huffman.h:228-234
-        // stage B: sibling and uncle counts
+        // stage B: sibling and uncle counts (branch-free: idle lanes look at the root)
         const uint32_t sib = is_hi ? lp.lo : lp.hi;
         const uint32_t uncle = (lg.lo == (uint32_t)c.par) ? lg.hi : lg.lo;
-        const bool has_sib = c.active && sib != kNil;
-        const bool has_unc = is_hi && c.has_g && uncle != kNil;
+        const bool has_sib = c.active & (sib != kNil);
+        const bool has_unc = is_hi & c.has_g & (uncle != kNil);
         const uint32_t fs = freq[has_sib ? (int)sib : kRoot];
         const uint32_t fu = freq[has_unc ? (int)uncle : kRoot];
-        bool flag = false;
-        if (has_sib) { flag = is_hi ? (fs > fc + 1) : (fc + 1 > fs); }
-        if (has_unc) { flag = flag || (fc + 1 > fu); }
-        if (c.levels >= kMaxFastDepth) { flag = true; }               // too deep: slow path
+        const uint32_t fc1 = fc + 1;
+        const uint32_t big = is_hi ? fs : fc1;                        // swap iff lo count > hi count
+        const uint32_t small = is_hi ? fc1 : fs;
+        const bool flag = (has_sib & (big > small)) | (has_unc & (fc1 > fu)) |
+                          (c.levels >= kMaxFastDepth);
         if (__ballot(flag) == 0) {
             if (c.holds) { freq[c.mine] = fc + 1; }
         } else {
@@ -570,6 +586,48 @@ struct Tree {
         return code;
     }
 };
+
+template <class T>
+__device__ __noinline__ uint32_t slow_insert(uint64_t* link, uint32_t* freq, TreeScratch* scratch,
+                                             uint32_t regs, int sym, int lane) {
+    T t;
+    t.link = link; t.freq = freq; t.scratch = scratch; t.lut = nullptr; t.lut_ok = 0;
+    t.unpack_regs(regs);
+    int ok = 1;
+    if (lane == 0) { ok = t.insert(sym) ? 1 : 0; }
+    const uint32_t r = t.pack_regs() | ((uint32_t)ok << 31);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+
+template <class T>
+__device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, TreeScratch* scratch,
+                                              uint32_t regs, int sym, int lane) {
+    T t;
+    t.link = link; t.freq = freq; t.scratch = scratch; t.lut = nullptr; t.lut_ok = 0;
+    t.unpack_regs(regs);
+    if (lane == 0) { t.freq[sym] += 1; t.changed(sym); }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs());
+}
+
+// decoder: table over the next 8 stream bits -> (node reached, bits used).
+// Entry = node | used << 10; a missing child gives node = kNil.
+template <class T>
+__device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut, int lane) {
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+        const int idx = lane + 64 * j;
+        int node = T::kRoot, used = 0;
+        for (int level = 0; level < 8; level++) {
+            const uint32_t kids = (uint32_t)(link[node] >> 30);
+            const int bit = (idx >> (7 - level)) & 1;
+            const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
+            used = level + 1;
+            node = child;
+            if (child == (int)kNil || child < (int)T::kRoot) { break; }
+        }
+        lut[idx] = (uint16_t)(node | (used << 10));
+    }
+}
 
 constexpr int kLitLeaves = 288;               // symbols 0..285 (+2 pad)
 constexpr int kLitNodes  = kLitLeaves + 288;  // root + <=285 splits (+pad)
