@@ -190,11 +190,19 @@ SQZ_API int  sqz_hip_get_finder(void);
 /* Live timing of the last kernels enqueued through this library on the
  * calling thread's context, measured with HIP events ON THE LAUNCH STREAM.
  * Enabled with sqz_hip_set_timing(1); values in milliseconds.               */
+enum {
+    SQZ_HIP_K_LZ77_SCAN = 0,      /* lz77_scan_kernel (brute-force finder)            */
+    SQZ_HIP_K_HUFFMAN_EMIT = 1,   /* huffman_emit_kernel                              */
+    SQZ_HIP_K_ENTROPY_DECODE = 2, /* entropy_decode_kernel                            */
+    SQZ_HIP_K_INDEX_SORT = 3,     /* index_sort_kernel   } indexed finder             */
+    SQZ_HIP_K_INDEX_MATCH = 4,    /* index_match_kernel  }                            */
+    SQZ_HIP_K_INDEX_PARSE = 5,    /* index_parse_kernel  }                            */
+    SQZ_HIP_K_LZ_EXPAND = 6,      /* lz_expand_kernel                                 */
+    SQZ_HIP_KERNELS = 8
+};
 typedef struct sqz_hip_timing {
-    float lz77_ms;
-    float huffman_ms;
-    float decode_ms;
-    uint32_t lz77_launches, huffman_launches, decode_launches;
+    float    ms[SQZ_HIP_KERNELS];        /* summed launch durations per kernel        */
+    uint32_t launches[SQZ_HIP_KERNELS];
 } sqz_hip_timing;
 SQZ_API void sqz_hip_set_timing(int enabled);
 SQZ_API int  sqz_hip_get_timing(sqz_hip_timing* out, int reset);

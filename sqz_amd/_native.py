@@ -22,10 +22,14 @@ class Sqz(C.Structure):
                 ("reserved", C.c_uint64 * 5)]
 
 
+KERNEL_NAMES = ["lz77_scan_kernel", "huffman_emit_kernel", "entropy_decode_kernel",
+                "index_sort_kernel", "index_match_kernel", "index_parse_kernel",
+                "lz_expand_kernel", "reserved"]
+
+
 class Timing(C.Structure):
-    _fields_ = [("lz77_ms", C.c_float), ("huffman_ms", C.c_float), ("decode_ms", C.c_float),
-                ("lz77_launches", C.c_uint32), ("huffman_launches", C.c_uint32),
-                ("decode_launches", C.c_uint32)]
+    """sqz_hip_timing: per-kernel summed durations (HIP events on the launch stream)."""
+    _fields_ = [("ms", C.c_float * 8), ("launches", C.c_uint32 * 8)]
 
 
 class SqueezeInterface(C.Structure):

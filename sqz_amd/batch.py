@@ -110,11 +110,11 @@ def set_timing(on: bool):
 
 
 def get_timing(reset=True):
+    """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
     t = N.Timing()
     N.lib().sqz_hip_get_timing(C.byref(t), 1 if reset else 0)
-    return {"lz77_ms": t.lz77_ms, "huffman_ms": t.huffman_ms, "decode_ms": t.decode_ms,
-            "lz77_launches": t.lz77_launches, "huffman_launches": t.huffman_launches,
-            "decode_launches": t.decode_launches}
+    return {N.KERNEL_NAMES[k]: (float(t.ms[k]), int(t.launches[k]))
+            for k in range(8) if t.launches[k] > 0}
 
 
 # ---- host-buffer flavour (numpy in / numpy out) ------------------------------

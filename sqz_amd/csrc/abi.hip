@@ -201,12 +201,17 @@ uint32_t match_groups_for(uint64_t avg_block_bytes) {
 void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
                 uint32_t window, uint32_t* tokens, uint32_t* counts,
                 uint32_t* work_a, uint32_t* work_m, uint64_t avg_block, hipStream_t st) {
-    SpanGuard g(st, 0);
     if (finder == 0 || work_a == nullptr || work_m == nullptr) {
+        SpanGuard g(st, SQZ_HIP_K_LZ77_SCAN);
         sqzk::launch_lz77_scan(d_in, d_in_off, n, window, tokens, counts, scan_waves(), st);
     } else {
-        sqzk::launch_lz77_index(d_in, d_in_off, n, window, work_a, tokens /* = buf_b */, work_m,
-                                tokens, counts, match_groups_for(avg_block), st);
+        { SpanGuard g(st, SQZ_HIP_K_INDEX_SORT);
+          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, st); }
+        { SpanGuard g(st, SQZ_HIP_K_INDEX_MATCH);
+          sqzk::launch_index_match(d_in, d_in_off, n, window, work_a, work_m,
+                                   match_groups_for(avg_block), st); }
+        { SpanGuard g(st, SQZ_HIP_K_INDEX_PARSE);
+          sqzk::launch_index_parse(d_in, d_in_off, n, work_m, tokens, counts, st); }
     }
 }
 
@@ -239,7 +244,7 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
                (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
                (uint32_t*)c.work_m.p, widest, st);
     {
-        SpanGuard g(st, 1);
+        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
         sqzk::launch_huffman_emit((const uint32_t*)c.tokens.p, (const uint64_t*)c.in_off.p,
                                  (const uint32_t*)c.tok_count.p, (uint8_t*)c.out.p,
                                  (const uint64_t*)c.out_off.p, (uint64_t*)c.out_bytes.p,
@@ -286,11 +291,16 @@ int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     {
-        SpanGuard g(st, 2);
-        sqzk::launch_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
-                            (const uint64_t*)c.out_off.p, (int32_t*)c.err.p,
-                            (uint64_t*)c.end_bit.p, (uint32_t*)c.tokens.p,
-                            (uint32_t*)c.tok_count.p, n, start_bit, st);
+        SpanGuard g(st, SQZ_HIP_K_ENTROPY_DECODE);
+        sqzk::launch_entropy_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p,
+                                    (const uint64_t*)c.out_off.p, (uint32_t*)c.tokens.p,
+                                    (uint32_t*)c.tok_count.p, (int32_t*)c.err.p,
+                                    (uint64_t*)c.end_bit.p, n, start_bit, st);
+    }
+    {
+        SpanGuard g(st, SQZ_HIP_K_LZ_EXPAND);
+        sqzk::launch_lz_expand((const uint32_t*)c.tokens.p, (const uint32_t*)c.tok_count.p,
+                               (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p, n, st);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -530,7 +540,7 @@ int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
         d_out_off == NULL || d_out_bytes == NULL || d_err == NULL) { return EINVAL; }
     const int e = device_ready();
     if (e != 0) { return e; }
-    SpanGuard g((hipStream_t)stream, 1);
+    SpanGuard g((hipStream_t)stream, SQZ_HIP_K_HUFFMAN_EMIT);
     sqzk::launch_huffman_emit(d_tokens, d_in_off, d_token_count, (uint8_t*)d_out, d_out_off,
                              d_out_bytes, d_err, n, 0, 0, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
@@ -574,9 +584,11 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     if (e != 0) { return e; }
     uint32_t* counts = (uint32_t*)d_scratch;
     uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + align_up((uint64_t)n * 4, 256));
-    SpanGuard g((hipStream_t)stream, 2);
-    sqzk::launch_decode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_err, nullptr,
-                        tokens, counts, n, 0, (hipStream_t)stream);
+    { SpanGuard g((hipStream_t)stream, SQZ_HIP_K_ENTROPY_DECODE);
+      sqzk::launch_entropy_decode((const uint8_t*)d_in, d_in_off, d_out_off, tokens, counts, d_err,
+                                  nullptr, n, 0, (hipStream_t)stream); }
+    { SpanGuard g((hipStream_t)stream, SQZ_HIP_K_LZ_EXPAND);
+      sqzk::launch_lz_expand(tokens, counts, (uint8_t*)d_out, d_out_off, n, (hipStream_t)stream); }
     return hip_errno(hipGetLastError());
 }
 
@@ -596,9 +608,7 @@ int sqz_hip_get_timing(sqz_hip_timing* out, int reset) {
     for (TimedSpan& s : t.spans) {
         float ms = 0.0f;
         if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-            if (s.kind == 0) { t.acc.lz77_ms += ms; t.acc.lz77_launches++; }
-            if (s.kind == 1) { t.acc.huffman_ms += ms; t.acc.huffman_launches++; }
-            if (s.kind == 2) { t.acc.decode_ms += ms; t.acc.decode_launches++; }
+            if (s.kind >= 0 && s.kind < SQZ_HIP_KERNELS) { t.acc.ms[s.kind] += ms; t.acc.launches[s.kind]++; }
         }
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);

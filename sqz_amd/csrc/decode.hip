@@ -256,13 +256,17 @@ void lz_expand_kernel(const uint32_t* __restrict__ tokens,
     flush_to(i);
 }
 
-void launch_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
-                   const uint64_t* out_off, int32_t* err, uint64_t* end_bit,
-                   uint32_t* tokens, uint32_t* tok_count,
-                   uint32_t n_blocks, uint64_t start_bit, hipStream_t stream) {
+void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
+                           uint32_t* tokens, uint32_t* tok_count, int32_t* err, uint64_t* end_bit,
+                           uint32_t n_blocks, uint64_t start_bit, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(entropy_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
                        in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+}
+
+void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,
+                      const uint64_t* out_off, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(lz_expand_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
                        tokens, tok_count, out, out_off, n_blocks);
 }

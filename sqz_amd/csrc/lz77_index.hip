@@ -311,17 +311,27 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
     if (lane == 0) { tok_count[b] = ntok; }
 }
 
-void launch_lz77_index(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
-                       uint32_t window, uint32_t* buf_a, uint32_t* buf_b, uint32_t* match,
-                       uint32_t* tokens, uint32_t* tok_count, uint32_t match_groups,
-                       hipStream_t stream) {
+void launch_index_sort(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(index_sort_kernel, dim3(n_blocks), dim3(kSortThreads), 0, stream,
-                       in, in_off, n_blocks, buf_a, buf_b, match /* scratch until index_match */);
+                       in, in_off, n_blocks, buf_a, buf_b, tmp);
+}
+
+void launch_index_match(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                        uint32_t window, const uint32_t* sorted, uint32_t* match,
+                        uint32_t match_groups, hipStream_t stream) {
+    if (n_blocks == 0) { return; }
     if (match_groups < 1) { match_groups = 1; }
     if (match_groups > 65535) { match_groups = 65535; }
     hipLaunchKernelGGL(index_match_kernel, dim3(n_blocks, match_groups), dim3(256), 0, stream,
-                       in, in_off, n_blocks, window, buf_a, match);
+                       in, in_off, n_blocks, window, sorted, match);
+}
+
+void launch_index_parse(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                        const uint32_t* match, uint32_t* tokens, uint32_t* tok_count,
+                        hipStream_t stream) {
+    if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(index_parse_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
                        in, in_off, n_blocks, match, tokens, tok_count);
 }

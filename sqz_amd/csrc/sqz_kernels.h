@@ -16,12 +16,16 @@ void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_bloc
                       int waves_per_stream, hipStream_t stream);
 
 // stage 1, indexed form: same tokens as launch_lz77_scan without visiting every
-// distance (lz77_index.hip).  buf_a / buf_b / match: one uint32 slot per input
-// byte each, addressed like `tokens` (buf_b may alias tokens).
-void launch_lz77_index(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
-                       uint32_t window, uint32_t* buf_a, uint32_t* buf_b, uint32_t* match,
-                       uint32_t* tokens, uint32_t* tok_count, uint32_t match_groups,
-                       hipStream_t stream);
+// distance (lz77_index.hip): sort -> match -> parse.  buf_a / buf_b / match: one
+// uint32 slot per input byte each, addressed like `tokens`.
+void launch_index_sort(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, hipStream_t stream);
+void launch_index_match(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                        uint32_t window, const uint32_t* sorted, uint32_t* match,
+                        uint32_t match_groups, hipStream_t stream);
+void launch_index_parse(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
+                        const uint32_t* match, uint32_t* tokens, uint32_t* tok_count,
+                        hipStream_t stream);
 
 // stage 2: adaptive-Huffman emit (squeeze.h:278-315, huffman.h, bitstream.h)
 void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
@@ -32,9 +36,10 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
 
 // decode (squeeze.h:502-551): entropy stage -> token words -> LZ77 expansion.
 // tokens: one uint32 slot per OUTPUT byte, addressed by out_off; tok_count[n].
-void launch_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out,
-                   const uint64_t* out_off, int32_t* err, uint64_t* end_bit,
-                   uint32_t* tokens, uint32_t* tok_count,
-                   uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
+void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
+                           uint32_t* tokens, uint32_t* tok_count, int32_t* err, uint64_t* end_bit,
+                           uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
+void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,
+                      const uint64_t* out_off, uint32_t n_blocks, hipStream_t stream);
 
 } // namespace sqzk
