@@ -197,7 +197,7 @@ uint32_t match_groups_for(uint64_t avg_block_bytes) {
     return (uint32_t)g;
 }
 
-// stage 1 on device buffers; work = 2 arrays of one uint32 slot per input byte
+// stage 1 on device buffers -> token words; work = 2 arrays of one uint32 slot per input byte
 void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
                 uint32_t window, uint32_t* tokens, uint32_t* counts,
                 uint32_t* work_a, uint32_t* work_m, uint64_t avg_block, hipStream_t st) {
@@ -212,6 +212,30 @@ void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
                                    match_groups_for(avg_block), st); }
         { SpanGuard g(st, SQZ_HIP_K_INDEX_PARSE);
           sqzk::launch_index_parse(d_in, d_in_off, n, work_m, tokens, counts, st); }
+    }
+}
+
+// the whole encode on device buffers.  Indexed finder: sort -> match -> emit (the
+// greedy step runs inside the emit kernel, no token array); scan finder: scan -> emit.
+void run_encode(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
+                uint32_t window, uint32_t* tokens, uint32_t* counts, uint32_t* work_a,
+                uint32_t* work_m, uint64_t avg_block, uint8_t* d_out, const uint64_t* d_out_off,
+                uint64_t* d_out_bytes, int32_t* d_err, uint64_t prefix_acc, int prefix_fill,
+                hipStream_t st) {
+    if (finder == 0) {
+        run_stage1(0, d_in, d_in_off, n, window, tokens, counts, nullptr, nullptr, avg_block, st);
+        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
+        sqzk::launch_huffman_emit(tokens, d_in_off, counts, d_out, d_out_off, d_out_bytes, d_err, n,
+                                  prefix_acc, prefix_fill, st);
+    } else {
+        { SpanGuard g(st, SQZ_HIP_K_INDEX_SORT);
+          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, st); }
+        { SpanGuard g(st, SQZ_HIP_K_INDEX_MATCH);
+          sqzk::launch_index_match(d_in, d_in_off, n, window, work_a, work_m,
+                                   match_groups_for(avg_block), st); }
+        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
+        sqzk::launch_huffman_emit_from_match(d_in, d_in_off, work_m, counts, d_out, d_out_off,
+                                             d_out_bytes, d_err, n, prefix_acc, prefix_fill, st);
     }
 }
 
@@ -240,16 +264,10 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     uint64_t widest = 0;
     for (uint32_t b = 0; b < n; b++) { widest = io[b + 1] - io[b] > widest ? io[b + 1] - io[b] : widest; }
-    run_stage1(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
+    run_encode(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
                (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
-               (uint32_t*)c.work_m.p, widest, st);
-    {
-        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
-        sqzk::launch_huffman_emit((const uint32_t*)c.tokens.p, (const uint64_t*)c.in_off.p,
-                                 (const uint32_t*)c.tok_count.p, (uint8_t*)c.out.p,
-                                 (const uint64_t*)c.out_off.p, (uint64_t*)c.out_bytes.p,
-                                 (int32_t*)c.err.p, n, prefix_acc, prefix_fill, st);
-    }
+               (uint32_t*)c.work_m.p, widest, (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
+               (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_bytes, c.out_bytes.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -560,12 +578,10 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + head);
     uint32_t* work_a = tokens + slots;
     uint32_t* work_m = work_a + slots;
-    run_stage1(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
-               work_a, work_m, slots / n, (hipStream_t)stream);
-    e = hip_errno(hipGetLastError());
-    if (e != 0) { return e; }
-    return sqz_hip_huffman_blocks(tokens, d_in_off, counts, n, d_out, d_out_off, d_out_bytes,
-                                  d_err, stream);
+    run_encode(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
+               work_a, work_m, slots / n, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, 0, 0,
+               (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
 }
 
 uint64_t sqz_hip_decode_scratch_bytes(uint32_t n, uint64_t total_out_bytes) {

@@ -157,10 +157,38 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
     }
 }
 
+// one token word -> its bit fields (squeeze.h:377-394 -> :278-315)
+__device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& pos, uint32_t t,
+                                           int lane, int& err) {
+    const bool is_match = (t & kTokMatch) != 0;
+    Code lc = {0, 0, 0};
+    int s_lit = (int)(t & 0xFFu);
+    if (is_match) {
+        lc = len_code((int)((t >> 16) & 0x1FFu));                     // squeeze.h:290-298
+        s_lit = kSymLen0 + lc.code;
+    }
+    emit_coded(q, lit, s_lit, kLitNyt, 9, lane, err);
+    if (is_match) {
+        if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
+        const Code pc = pos_code((int)(t & 0x7FFFu));                 // squeeze.h:300-315
+        emit_coded(q, pos, pc.code, kPosNyt, 5, lane, err);
+        if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
+    }
+    if (q.count > kQueue - kQueueRoom) { q.pack(lane); }
+    if (q.error != 0) { err = q.error; }
+    if (lit.fault | pos.fault) { err = kE2BIG; }
+}
+
+// kFromMatch = false: token words of stage 1 (any finder)
+// kFromMatch = true : the indexed finder's match table; the greedy step
+//                     (squeeze.h:377-394) happens here, no token array in between
+template <bool kFromMatch>
 __global__ __launch_bounds__(kWave)
-void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
-                         const uint64_t* __restrict__ tok_off,
-                         const uint32_t* __restrict__ tok_count,
+void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words | match table
+                         const uint64_t* __restrict__ tok_off,   // = in_off
+                         const uint32_t* __restrict__ tok_count, // unused when kFromMatch
+                         uint32_t* __restrict__ tok_count_out,   // kFromMatch: tokens per stream (or null)
+                         const uint8_t* __restrict__ in,         // input bytes (kFromMatch)
                          uint8_t* __restrict__ out,
                          const uint64_t* __restrict__ out_off,
                          uint64_t* __restrict__ out_bytes,
@@ -182,8 +210,8 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     }
     __syncthreads();
 
-    const uint32_t* tok = tokens + uni64(tok_off[b]);
-    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+    const uint64_t t0 = uni64(tok_off[b]), t1 = uni64(tok_off[b + 1]);
+    const uint32_t* tok = tokens + t0;
 
     BitQueue q;
     q.lds = &lds;
@@ -199,32 +227,46 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
-    for (uint32_t base = 0; base < count && err == 0; base += kTokStrip) {
-        const uint32_t left = count - base;
-        const uint32_t take = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
-        __syncthreads();
-        for (uint32_t k = lane; k < take; k += kWave) { lds.strip[k] = tok[base + k]; }
-        __syncthreads();
-        for (uint32_t k = 0; k < take && err == 0; k++) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.strip[k]);
-            const bool is_match = (t & kTokMatch) != 0;
-            Code lc = {0, 0, 0};
-            int s_lit = (int)(t & 0xFFu);
-            if (is_match) {
-                lc = len_code((int)((t >> 16) & 0x1FFu));             // squeeze.h:290-298
-                s_lit = kSymLen0 + lc.code;
+    if (!kFromMatch) {
+        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+        for (uint32_t base = 0; base < count && err == 0; base += kTokStrip) {
+            const uint32_t left = count - base;
+            const uint32_t take = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
+            __syncthreads();
+            for (uint32_t k = lane; k < take; k += kWave) { lds.strip[k] = tok[base + k]; }
+            __syncthreads();
+            for (uint32_t k = 0; k < take && err == 0; k++) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.strip[k]);
+                emit_token(q, lit, pos, t, lane, err);
             }
-            emit_coded(q, lit, s_lit, kLitNyt, 9, lane, err);
-            if (is_match) {
-                if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
-                const Code pc = pos_code((int)(t & 0x7FFFu));         // squeeze.h:300-315
-                emit_coded(q, pos, pc.code, kPosNyt, 5, lane, err);
-                if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
-            }
-            if (q.count > kQueue - kQueueRoom) { q.pack(lane); }
-            if (q.error != 0) { err = q.error; }
-            if (lit.fault | pos.fault) { err = kE2BIG; }
         }
+    } else {
+        const uint8_t* src = in + t0;
+        const uint64_t bytes = t1 - t0;
+        uint64_t i = 0;
+        uint32_t ntok = 0;
+        while (i < bytes && err == 0) {
+            // strip: match words of positions [i, i+have); the byte rides in bits 24..30 ...
+            const uint64_t sbase = i;
+            const uint64_t left = bytes - sbase;
+            const uint32_t have = left < (uint64_t)kTokStrip ? (uint32_t)left : (uint32_t)kTokStrip;
+            __syncthreads();
+            for (uint32_t k = lane; k < have; k += kWave) {
+                // a literal is stored as its byte, a match as kTokMatch | len<<16 | dist;
+                // the last two positions have no 3-byte prefix (always literals)
+                const uint32_t m = (sbase + k + 2 < bytes) ? tok[sbase + k] : 0u;
+                lds.strip[k] = m != 0 ? (kTokMatch | m) : (uint32_t)src[sbase + k];
+            }
+            __syncthreads();
+            while (i < sbase + have && err == 0) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)lds.strip[(uint32_t)(i - sbase)]);
+                i += (t & kTokMatch) ? (uint64_t)((t >> 16) & 0x1FFu) : 1ull;
+                ntok++;
+                emit_token(q, lit, pos, t, lane, err);
+            }
+        }
+        if (lane == 0 && tok_count_out != nullptr) { tok_count_out[b] = ntok; }
     }
 
     if (err == 0) { q.flush(lane); err = q.error; }
@@ -241,9 +283,20 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          int32_t* err, uint32_t n_blocks,
                          uint64_t prefix_acc, int prefix_fill, hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(huffman_emit_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       tokens, tok_off, tok_count, out, out_off, out_bytes, err,
-                       n_blocks, prefix_acc, prefix_fill);
+    hipLaunchKernelGGL(huffman_emit_kernel<false>, dim3(n_blocks), dim3(kWave), 0, stream,
+                       tokens, tok_off, tok_count, (uint32_t*)nullptr, (const uint8_t*)nullptr, out,
+                       out_off, out_bytes, err, n_blocks, prefix_acc, prefix_fill);
+}
+
+void launch_huffman_emit_from_match(const uint8_t* in, const uint64_t* in_off,
+                                    const uint32_t* match, uint32_t* tok_count_out, uint8_t* out,
+                                    const uint64_t* out_off, uint64_t* out_bytes,
+                                    int32_t* err, uint32_t n_blocks,
+                                    uint64_t prefix_acc, int prefix_fill, hipStream_t stream) {
+    if (n_blocks == 0) { return; }
+    hipLaunchKernelGGL(huffman_emit_kernel<true>, dim3(n_blocks), dim3(kWave), 0, stream,
+                       match, in_off, (const uint32_t*)nullptr, tok_count_out, in, out, out_off,
+                       out_bytes, err, n_blocks, prefix_acc, prefix_fill);
 }
 
 } // namespace sqzk
