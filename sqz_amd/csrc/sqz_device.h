@@ -523,33 +523,31 @@ struct Tree {
     // leaf -> root walk, three levels per dependent LDS read; lane k receives
     // level k (0 = the leaf).  Uniform control flow.
     __device__ __forceinline__ Chain chain_up(int s, int lane) const {
+        // the leaf's own word gives its depth, so the walk has a known trip count:
+        // one dependent read per three levels, no end-of-chain tests inside
+        const uint64_t w0 = uni64(link[s]);
+        const int levels = (int)((uint32_t)(w0 >> 50) & 0x3Fu);
+        const int stop = levels < kMaxFastDepth ? levels : kMaxFastDepth;
+        uint32_t w = (uint32_t)w0;
         int mine = (lane == 0) ? s : (int)kNil;
-        int a = s, k = 0;
-        for (;;) {
-            // low half of the word: up | up2 | up3
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)reinterpret_cast<const uint32_t*>(link)[2 * a]);
-            const uint32_t u1 = w & 0x3FFu, u2 = (w >> 10) & 0x3FFu, u3 = (w >> 20) & 0x3FFu;
-            if (u1 == kNil) { break; }
-            // lanes k+1..k+3 take up / up2 / up3 (a nil stays nil)
-            const int f = lane - k;
-            const bool take = (f >= 1 && f <= 3);
-            const uint32_t pick = (w >> (take ? 10 * (f - 1) : 0)) & 0x3FFu;
-            mine = take ? (int)pick : mine;
-            if (u2 == kNil) { k += 1; break; }
-            if (u3 == kNil) { k += 2; break; }
+        int k = 0;
+        while (k < stop) {
+            const uint32_t f = (uint32_t)(lane - k - 1);          // 0..2: up / up2 / up3
+            const uint32_t pick = (w >> (f < 3u ? 10u * f : 0u)) & 0x3FFu;
+            mine = (f < 3u) ? (int)pick : mine;
             k += 3;
-            a = (int)u3;
-            if (a == kRoot || k >= kMaxFastDepth) { break; }
+            if (k >= stop) { break; }
+            const int a = (int)((w >> 20) & 0x3FFu);
+            w = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(link)[2 * a]);
         }
         Chain c;
-        c.mine = mine;
+        c.mine = mine;                       // lanes beyond `levels` hold nil (or junk: not `holds`)
         c.par = lane_above(mine);            // lane k+1 holds the parent
         c.gpar = lane_above(c.par);
-        c.levels = k;
-        c.holds = lane <= k;
-        c.active = lane < k;
-        c.has_g = lane + 1 < k;
+        c.levels = levels;
+        c.holds = lane <= levels;
+        c.active = lane < levels;
+        c.has_g = lane + 1 < levels;
         return c;
     }
 
