@@ -554,23 +554,20 @@ struct Tree {
     // huffman_inc_frequency for an ATTACHED leaf s whose chain is `c`.
     // Returns the ballot of "my node is the hi child" (the stream-order code).
     __device__ __forceinline__ uint64_t bump_wave(int s, const Chain& c, int lane) {
-        // stage A: my count, my parent's and my grandparent's links
+        // stage A: my count and my parent's links
         const int i_mine = c.holds ? c.mine : kRoot;
         const int i_par = c.active ? c.par : kRoot;
-        const int i_gpar = c.has_g ? c.gpar : kRoot;
         const uint32_t fc = freq[i_mine];
         const Node lp = ld(i_par);
-        const Node lg = ld(i_gpar);
-        const bool is_hi = c.active && (lp.hi == (uint32_t)c.mine);
+        const bool is_hi = c.active & (lp.hi == (uint32_t)c.mine);
         const uint64_t code = __ballot(is_hi);
         if (complete != 0 || depth >= 63) { complete = 1; return code; }   // huffman.h:228-234
-        // stage B: sibling and uncle counts (branch-free: idle lanes look at the root)
+        // stage B: my sibling's count; my uncle is my parent's sibling = the lane above
         const uint32_t sib = is_hi ? lp.lo : lp.hi;
-        const uint32_t uncle = (lg.lo == (uint32_t)c.par) ? lg.hi : lg.lo;
         const bool has_sib = c.active & (sib != kNil);
-        const bool has_unc = is_hi & c.has_g & (uncle != kNil);
         const uint32_t fs = freq[has_sib ? (int)sib : kRoot];
-        const uint32_t fu = freq[has_unc ? (int)uncle : kRoot];
+        const uint32_t fu = (uint32_t)lane_above((int)fs);
+        const bool has_unc = is_hi & c.has_g & (lane_above(has_sib ? 1 : 0) == 1);
         const uint32_t fc1 = fc + 1;
         const uint32_t big = is_hi ? fs : fc1;                        // swap iff lo count > hi count
         const uint32_t small = is_hi ? fc1 : fs;
