@@ -86,11 +86,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters when ranks are rehearsed on fewer devices
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SQZ_BENCH_BACKEND", "nccl")      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n, bb, wb = args.blocks, args.block_bytes, args.win_bits
     info = sqz_amd.device_info()
@@ -104,7 +110,10 @@ def main():
     derr = torch.zeros(n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
+    red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -148,9 +157,9 @@ def main():
         assert torch.equal(d_back, d_in), "round trip differs"
 
     if world > 1:
-        enc_s = shard.max_over_ranks(enc_s, dev)
-        dec_s = shard.max_over_ranks(dec_s, dev)
-        comp_total = shard.sum_over_ranks(float(comp_bytes), dev)
+        enc_s = shard.max_over_ranks(enc_s, red_dev)
+        dec_s = shard.max_over_ranks(dec_s, red_dev)
+        comp_total = shard.sum_over_ranks(float(comp_bytes), red_dev)
     else:
         comp_total = float(comp_bytes)
 
