@@ -26,7 +26,6 @@ constexpr int kQueueRoom = 8;        // a token adds at most 6 fields (+2 for a 
 
 struct EmitLds {
     EntropyLds entropy;
-    uint32_t   strip[kTokStrip];
     uint64_t   field[kQueue];        // width << 32 | value   (width 1..32)
     uint64_t   image[kQueue / 2 + 2];// packed bits of one batch, stream order = MSB first
 };
@@ -157,7 +156,7 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
     }
 }
 
-// one token word -> its bit fields (squeeze.h:377-394 -> :278-315)
+// one token word -> its bit fields (squeeze.h:377-394 -> :278-315), one symbol at a time
 __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& pos, uint32_t t,
                                            int lane, int& err) {
     const bool is_match = (t & kTokMatch) != 0;
@@ -174,14 +173,48 @@ __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& p
         emit_coded(q, pos, pc.code, kPosNyt, 5, lane, err);
         if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
     }
-    if (q.count > kQueue - kQueueRoom) { q.pack(lane); }
     if (q.error != 0) { err = q.error; }
     if (lit.fault | pos.fault) { err = kE2BIG; }
 }
 
-// kFromMatch = false: token words of stage 1 (any finder)
-// kFromMatch = true : the indexed finder's match table; the greedy step
-//                     (squeeze.h:377-394) happens here, no token array in between
+// The token source: a 128-entry window of token words in two VGPRs (lane j holds
+// entries j and 64+j), refilled with coalesced loads; a word is fetched with
+// v_readlane -- no LDS round trip in front of every symbol.
+//   kFromMatch = false: entry k = token word k of stage 1 (any finder)
+//   kFromMatch = true : entry p = what starts at byte p according to the indexed
+//                       finder's match table (kTokMatch|len<<16|dist, or the byte);
+//                       the greedy step (squeeze.h:377-394) is the cursor advance
+template <bool kFromMatch>
+struct TokenWindow {
+    const uint32_t* words;    // token words | match table
+    const uint8_t*  bytes_in; // input bytes (kFromMatch)
+    uint64_t total;           // tokens | bytes
+    uint64_t wbase;           // entry held by lane 0 of `cur`
+    uint32_t cur, nxt;
+
+    __device__ __forceinline__ uint32_t load(uint64_t at, int lane) const {
+        const uint64_t k = at + (uint64_t)lane;
+        if (k >= total) { return 0u; }
+        if (!kFromMatch) { return words[k]; }
+        const uint32_t m = (k + 2 < total) ? words[k] : 0u;          // last 2 bytes: literals
+        return m != 0 ? (kTokMatch | m) : (uint32_t)bytes_in[k];
+    }
+    __device__ __forceinline__ void open(uint64_t at, int lane) {
+        wbase = at;
+        cur = load(at, lane);
+        nxt = load(at + kWave, lane);
+    }
+    __device__ __forceinline__ uint32_t at(uint64_t pos, int lane) {
+        if (pos - wbase >= 2 * kWave) { open(pos, lane); }             // jumped past both rows
+        else if (pos - wbase >= kWave) {                               // slide one row
+            cur = nxt;
+            wbase += kWave;
+            nxt = load(wbase + kWave, lane);
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(pos - wbase));
+    }
+};
+
 template <bool kFromMatch>
 __global__ __launch_bounds__(kWave)
 void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words | match table
@@ -211,7 +244,6 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
     __syncthreads();
 
     const uint64_t t0 = uni64(tok_off[b]), t1 = uni64(tok_off[b + 1]);
-    const uint32_t* tok = tokens + t0;
 
     BitQueue q;
     q.lds = &lds;
@@ -227,47 +259,94 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
-    if (!kFromMatch) {
-        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
-        for (uint32_t base = 0; base < count && err == 0; base += kTokStrip) {
-            const uint32_t left = count - base;
-            const uint32_t take = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
-            __syncthreads();
-            for (uint32_t k = lane; k < take; k += kWave) { lds.strip[k] = tok[base + k]; }
-            __syncthreads();
-            for (uint32_t k = 0; k < take && err == 0; k++) {
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.strip[k]);
-                emit_token(q, lit, pos, t, lane, err);
+    TokenWindow<kFromMatch> win;
+    win.words = tokens + t0;
+    win.bytes_in = kFromMatch ? in + t0 : nullptr;
+    win.total = kFromMatch ? (t1 - t0)
+                           : (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+    win.open(0, lane);
+
+    uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
+    uint32_t* const freq = lds.entropy.lit_freq;
+    uint64_t cursor = 0;
+    uint32_t ntok = 0;
+    while (cursor < win.total && err == 0) {
+        // ---- gather up to 4 symbols (whole tokens) -------------------------------
+        uint32_t tw[kBatch] = {0, 0, 0, 0};   // token words of this step: tw[j] valid iff j < nt
+        int s0 = kUnifiedDummy, s1 = kUnifiedDummy, s2 = kUnifiedDummy, s3 = kUnifiedDummy;
+        int nt = 0, ns = 0;
+        bool open_step = true;
+        uint64_t c2 = cursor;
+        auto put = [&](int leaf) {          // uniform selects keep the ids in SGPRs
+            s0 = ns == 0 ? leaf : s0;
+            s1 = ns == 1 ? leaf : s1;
+            s2 = ns == 2 ? leaf : s2;
+            s3 = ns == 3 ? leaf : s3;
+            ns++;
+        };
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            if (open_step && c2 < win.total && ns < kBatch) {
+                const uint32_t t = win.at(c2, lane);
+                const bool is_match = (t & kTokMatch) != 0;
+                if (is_match && ns + 2 > kBatch) {
+                    open_step = false;       // no room for this match: close the step
+                } else {
+                    tw[j] = t;
+                    nt = j + 1;
+                    if (is_match) {
+                        put(kSymLen0 + len_code((int)((t >> 16) & 0x1FFu)).code);
+                        put(kLitNodes + pos_code((int)(t & 0x7FFFu)).code);
+                    } else {
+                        put((int)(t & 0xFFu));
+                    }
+                    c2 += (kFromMatch && is_match) ? (uint64_t)((t >> 16) & 0x1FFu) : 1ull;
+                }
+            } else {
+                open_step = false;
             }
         }
-    } else {
-        const uint8_t* src = in + t0;
-        const uint64_t bytes = t1 - t0;
-        uint64_t i = 0;
-        uint32_t ntok = 0;
-        while (i < bytes && err == 0) {
-            // strip: match words of positions [i, i+have); the byte rides in bits 24..30 ...
-            const uint64_t sbase = i;
-            const uint64_t left = bytes - sbase;
-            const uint32_t have = left < (uint64_t)kTokStrip ? (uint32_t)left : (uint32_t)kTokStrip;
-            __syncthreads();
-            for (uint32_t k = lane; k < have; k += kWave) {
-                // a literal is stored as its byte, a match as kTokMatch | len<<16 | dist;
-                // the last two positions have no 3-byte prefix (always literals)
-                const uint32_t m = (sbase + k + 2 < bytes) ? tok[sbase + k] : 0u;
-                lds.strip[k] = m != 0 ? (kTokMatch | m) : (uint32_t)src[sbase + k];
+        // ---- all of them at once, if no link can change (sqz_device.h) -------------
+        BatchOut bo;
+        bool done = false;
+        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63;
+        if (!frozen && ns > 1) {
+            done = bump_batch(link, freq, s0, s1, s2, s3, ns, lane, bo);
+        }
+        if (done) {
+            int slot = 0;
+#pragma unroll
+            for (int j = 0; j < kBatch; j++) {
+                if (j < nt) {
+                    const uint32_t t = tw[j];
+                    const uint32_t c = (uint32_t)(bo.code_bits >> (16 * slot)) & 0xFFFFu;
+                    const int d = (int)((bo.depths >> (8 * slot)) & 0xFFu);
+                    q.push32(c, d, lane);
+                    slot++;
+                    if (t & kTokMatch) {
+                        const Code lc = len_code((int)((t >> 16) & 0x1FFu));
+                        if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
+                        const uint32_t c1 = (uint32_t)(bo.code_bits >> (16 * slot)) & 0xFFFFu;
+                        const int d1 = (int)((bo.depths >> (8 * slot)) & 0xFFu);
+                        q.push32(c1, d1, lane);
+                        slot++;
+                        const Code pc = pos_code((int)(t & 0x7FFFu));
+                        if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
+                    }
+                }
             }
-            __syncthreads();
-            while (i < sbase + have && err == 0) {
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(
-                    (int)lds.strip[(uint32_t)(i - sbase)]);
-                i += (t & kTokMatch) ? (uint64_t)((t >> 16) & 0x1FFu) : 1ull;
-                ntok++;
-                emit_token(q, lit, pos, t, lane, err);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kBatch; j++) {
+                if (j < nt && err == 0) { emit_token(q, lit, pos, tw[j], lane, err); }
             }
         }
-        if (lane == 0 && tok_count_out != nullptr) { tok_count_out[b] = ntok; }
+        cursor = c2;
+        ntok += (uint32_t)nt;
+        if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
+        if (q.error != 0) { err = q.error; }
     }
+    if (kFromMatch && lane == 0 && tok_count_out != nullptr) { tok_count_out[b] = ntok; }
 
     if (err == 0) { q.flush(lane); err = q.error; }
     else { q.pack(lane); }

@@ -646,6 +646,93 @@ struct EntropyLds {
     TreeScratch scratch;
 };
 
+// ---------------------------------------------------------------------------
+// Four symbols per step.  Both trees are one array pair (pos ids + kLitNodes),
+// quarter q of the wave (one DPP row = 16 lanes) owns symbol q, its lane l owns
+// level l of that symbol's leaf->root chain.
+//
+// Exactness: the reference updates the symbols one after another.  It would
+// change no link during the whole step if, for every chain node c (parent p,
+// sibling s, uncle u; f0 = counts before the step, n(c) = chains through c):
+//     c is lo(p):                 f0(c) + n(c) <= f0(s)      (never overtakes s)
+//     c is hi(p):                 f0(s) <= f0(c) + 1         (no inversion waiting)
+//     c is hi(p), p not the root: f0(c) + n(c) <= f0(u)      (never overtakes u)
+// (induction over the sequential updates: every count only grows, c's count
+// never exceeds f0(c)+n(c), s and u never drop below f0; a lo sibling that is
+// itself on a chain is covered by its own first test).  Then the result of the
+// step is f0 + n on every chain node and every code is the static tree's, which is
+// what the lanes produce with LDS atomic adds.  If any test fails, the adds are
+// undone and the caller feeds the symbols to the one-at-a-time path, so the tests
+// may be conservative but the output is always the reference's.
+constexpr int kBatch = 4;
+constexpr int kBatchDepth = 15;
+constexpr int kUnifiedDummy = kLitLeaves;        // the lit root: always a valid slot
+
+__device__ __forceinline__ int row_above(int v, int fill) {          // lane l <- lane l+1, same row
+    return __builtin_amdgcn_update_dpp(fill, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+}
+
+struct BatchOut {
+    uint64_t code_bits;      // quarter q's code = bits 16q .. 16q+depth-1 (stream order)
+    uint32_t depths;         // depth of symbol q in byte q
+};
+
+__device__ __forceinline__ bool bump_batch(uint64_t* link, uint32_t* freq,
+                                           int s0, int s1, int s2, int s3, int n, int lane,
+                                           BatchOut& out) {
+    const int q = lane >> 4, l = lane & 15;
+    const bool live = q < n;
+    int leaf = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));     // unified id
+    leaf = live ? leaf : kUnifiedDummy;
+    const int base = leaf >= kLitNodes ? kLitNodes : 0;
+    const uint64_t w0 = link[leaf];
+    const int depth = (int)((uint32_t)(w0 >> 50) & 0x3Fu);
+    const bool bad = live & (depth == 0 || depth > kBatchDepth);     // unseen / too deep
+    uint32_t w = (uint32_t)w0;
+    int mine = (l == 0) ? (leaf - base) : (int)kNil;                   // ids local to the tree
+    int k = 0;
+#pragma unroll 1
+    for (int it = 0; it < 5; it++) {
+        const uint32_t f = (uint32_t)(l - k - 1);
+        const uint32_t pick = (w >> (f < 3u ? 10u * f : 0u)) & 0x3FFu;
+        mine = (f < 3u) ? (int)pick : mine;
+        k += 3;
+        const bool more = live & !bad & (k < depth);
+        if (__ballot(more) == 0) { break; }
+        const int a = (int)((w >> 20) & 0x3FFu);
+        if (more) { w = reinterpret_cast<const uint32_t*>(link)[2 * (base + a)]; }
+    }
+    const bool holds = live & !bad & (l <= depth);
+    const bool active = live & !bad & (l < depth);
+    const bool has_g = live & !bad & (l + 1 < depth);
+    const int par = row_above(mine, (int)kNil);
+    const int i_mine = holds ? base + mine : kUnifiedDummy;
+    const int i_par = active ? base + par : kUnifiedDummy;
+    const uint32_t fc = freq[i_mine];
+    const Node lp = unpack(link[i_par]);
+    const bool is_hi = active & (lp.hi == (uint32_t)mine);
+    const uint32_t sib = is_hi ? lp.lo : lp.hi;
+    const bool has_sib = active & (sib != kNil);
+    const uint32_t fs = freq[has_sib ? base + (int)sib : kUnifiedDummy];
+    const uint32_t fu = (uint32_t)row_above((int)fs, 0);
+    const bool has_unc = is_hi & has_g & (row_above(has_sib ? 1 : 0, 0) == 1);
+    // all reads above see the counts before the step; now add
+    if (holds) { atomicAdd(&freq[i_mine], 1u); }
+    const uint32_t ff = freq[i_mine];                                   // f0 + n
+    const bool flag = bad | (has_sib & (is_hi ? (fs > fc + 1) : (ff > fs))) | (has_unc & (ff > fu));
+    if (__ballot(flag) != 0) {
+        if (holds) { atomicSub(&freq[i_mine], 1u); }
+        return false;
+    }
+    out.code_bits = __ballot(is_hi);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(depth, 0);
+    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane(depth, 16);
+    const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane(depth, 32);
+    const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane(depth, 48);
+    out.depths = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+    return true;
+}
+
 __device__ __forceinline__ void bind(LitTree& lit, PosTree& pos, EntropyLds* s) {
     lit.link = s->lit_link; lit.freq = s->lit_freq; lit.scratch = &s->scratch; lit.lut = nullptr;
     pos.link = s->pos_link; pos.freq = s->pos_freq; pos.scratch = &s->scratch; pos.lut = nullptr;
