@@ -184,35 +184,46 @@ __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& p
 //   kFromMatch = true : entry p = what starts at byte p according to the indexed
 //                       finder's match table (kTokMatch|len<<16|dist, or the byte);
 //                       the greedy step (squeeze.h:377-394) is the cursor advance
+// Offsets are 32-bit: a stream is at most 2^31 bytes (include/sqz/sqz.h).
 template <bool kFromMatch>
 struct TokenWindow {
     const uint32_t* words;    // token words | match table
     const uint8_t*  bytes_in; // input bytes (kFromMatch)
-    uint64_t total;           // tokens | bytes
-    uint64_t wbase;           // entry held by lane 0 of `cur`
+    uint32_t total;           // tokens | bytes
+    uint32_t wbase;           // entry held by lane 0 of `cur`
     uint32_t cur, nxt;
 
-    __device__ __forceinline__ uint32_t load(uint64_t at, int lane) const {
-        const uint64_t k = at + (uint64_t)lane;
+    __device__ __forceinline__ uint32_t load(uint32_t at, int lane) const {
+        const uint32_t k = at + (uint32_t)lane;
         if (k >= total) { return 0u; }
         if (!kFromMatch) { return words[k]; }
         const uint32_t m = (k + 2 < total) ? words[k] : 0u;          // last 2 bytes: literals
         return m != 0 ? (kTokMatch | m) : (uint32_t)bytes_in[k];
     }
-    __device__ __forceinline__ void open(uint64_t at, int lane) {
+    __device__ __forceinline__ void open(uint32_t at, int lane) {
         wbase = at;
         cur = load(at, lane);
         nxt = load(at + kWave, lane);
     }
-    __device__ __forceinline__ uint32_t at(uint64_t pos, int lane) {
-        if (pos - wbase >= 2 * kWave) { open(pos, lane); }             // jumped past both rows
-        else if (pos - wbase >= kWave) {                               // slide one row
-            cur = nxt;
-            wbase += kWave;
-            nxt = load(wbase + kWave, lane);
-        }
-        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(pos - wbase));
+    // once per step: afterwards entries [pos, pos+64) are in the window
+    __device__ __forceinline__ void cover(uint32_t pos, int lane) {
+        const uint32_t d = pos - wbase;
+        if (d >= 2 * kWave) { open(pos, lane); }
+        else if (d >= kWave) { cur = nxt; wbase += kWave; nxt = load(wbase + kWave, lane); }
     }
+    __device__ __forceinline__ bool has(uint32_t pos) const { return pos - wbase < 2 * kWave; }
+    __device__ __forceinline__ uint32_t get(uint32_t pos) const {      // has(pos)
+        const uint32_t d = pos - wbase;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d & 63u));
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)(d & 63u));
+        return d < kWave ? a : b;
+    }
+};
+
+// what one token needs on the way out: its symbols' ids and the extra-bit fields
+struct TokenPlan {
+    uint32_t word;
+    uint32_t lx, px;          // extra bits (value | width << 16) for length / distance
 };
 
 template <bool kFromMatch>
@@ -262,21 +273,21 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
     TokenWindow<kFromMatch> win;
     win.words = tokens + t0;
     win.bytes_in = kFromMatch ? in + t0 : nullptr;
-    win.total = kFromMatch ? (t1 - t0)
-                           : (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+    win.total = kFromMatch ? (uint32_t)(t1 - t0)
+                           : (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
     win.open(0, lane);
 
     uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
     uint32_t* const freq = lds.entropy.lit_freq;
-    uint64_t cursor = 0;
-    uint32_t ntok = 0;
+    uint32_t cursor = 0, ntok = 0;
     while (cursor < win.total && err == 0) {
-        // ---- gather up to 4 symbols (whole tokens) -------------------------------
-        uint32_t tw[kBatch] = {0, 0, 0, 0};   // token words of this step: tw[j] valid iff j < nt
+        win.cover(cursor, lane);
+        // ---- plan up to 4 symbols (whole tokens) ------------------------------------
+        TokenPlan tp[kBatch];
         int s0 = kUnifiedDummy, s1 = kUnifiedDummy, s2 = kUnifiedDummy, s3 = kUnifiedDummy;
         int nt = 0, ns = 0;
         bool open_step = true;
-        uint64_t c2 = cursor;
+        uint32_t c2 = cursor;
         auto put = [&](int leaf) {          // uniform selects keep the ids in SGPRs
             s0 = ns == 0 ? leaf : s0;
             s1 = ns == 1 ? leaf : s1;
@@ -286,27 +297,32 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
         };
 #pragma unroll
         for (int j = 0; j < kBatch; j++) {
-            if (open_step && c2 < win.total && ns < kBatch) {
-                const uint32_t t = win.at(c2, lane);
-                const bool is_match = (t & kTokMatch) != 0;
-                if (is_match && ns + 2 > kBatch) {
-                    open_step = false;       // no room for this match: close the step
-                } else {
-                    tw[j] = t;
+            tp[j].word = 0; tp[j].lx = 0; tp[j].px = 0;
+            if (open_step && c2 < win.total && ns < kBatch && win.has(c2)) {
+                const uint32_t t = win.get(c2);
+                if ((t & kTokMatch) == 0) {
+                    tp[j].word = t;
                     nt = j + 1;
-                    if (is_match) {
-                        put(kSymLen0 + len_code((int)((t >> 16) & 0x1FFu)).code);
-                        put(kLitNodes + pos_code((int)(t & 0x7FFFu)).code);
-                    } else {
-                        put((int)(t & 0xFFu));
-                    }
-                    c2 += (kFromMatch && is_match) ? (uint64_t)((t >> 16) & 0x1FFu) : 1ull;
+                    put((int)(t & 0xFFu));
+                    c2 += 1;
+                } else if (ns + 2 <= kBatch) {
+                    const Code lc = len_code((int)((t >> 16) & 0x1FFu));          // squeeze.h:290-298
+                    const Code pc = pos_code((int)(t & 0x7FFFu));                 // squeeze.h:300-315
+                    tp[j].word = t;
+                    tp[j].lx = (uint32_t)lc.extra | ((uint32_t)lc.xbits << 16);
+                    tp[j].px = (uint32_t)pc.extra | ((uint32_t)pc.xbits << 16);
+                    nt = j + 1;
+                    put(kSymLen0 + lc.code);
+                    put(kLitNodes + pc.code);
+                    c2 += kFromMatch ? ((t >> 16) & 0x1FFu) : 1u;
+                } else {
+                    open_step = false;       // no room for this match: close the step
                 }
             } else {
                 open_step = false;
             }
         }
-        // ---- all of them at once, if no link can change (sqz_device.h) -------------
+        // ---- all of them at once, if no link can change (sqz_device.h) ---------------
         BatchOut bo;
         bool done = false;
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63;
@@ -314,31 +330,25 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
             done = bump_batch(link, freq, s0, s1, s2, s3, ns, lane, bo);
         }
         if (done) {
-            int slot = 0;
+            uint64_t codes = bo.code_bits;
+            uint32_t depths = bo.depths;
 #pragma unroll
             for (int j = 0; j < kBatch; j++) {
                 if (j < nt) {
-                    const uint32_t t = tw[j];
-                    const uint32_t c = (uint32_t)(bo.code_bits >> (16 * slot)) & 0xFFFFu;
-                    const int d = (int)((bo.depths >> (8 * slot)) & 0xFFu);
-                    q.push32(c, d, lane);
-                    slot++;
-                    if (t & kTokMatch) {
-                        const Code lc = len_code((int)((t >> 16) & 0x1FFu));
-                        if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
-                        const uint32_t c1 = (uint32_t)(bo.code_bits >> (16 * slot)) & 0xFFFFu;
-                        const int d1 = (int)((bo.depths >> (8 * slot)) & 0xFFu);
-                        q.push32(c1, d1, lane);
-                        slot++;
-                        const Code pc = pos_code((int)(t & 0x7FFFu));
-                        if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
+                    q.push32((uint32_t)codes & 0xFFFFu, (int)(depths & 0xFFu), lane);
+                    codes >>= 16; depths >>= 8;
+                    if (tp[j].word & kTokMatch) {
+                        if (tp[j].lx >> 16) { q.push_lsb(tp[j].lx & 0xFFFFu, (int)(tp[j].lx >> 16), lane); }
+                        q.push32((uint32_t)codes & 0xFFFFu, (int)(depths & 0xFFu), lane);
+                        codes >>= 16; depths >>= 8;
+                        if (tp[j].px >> 16) { q.push_lsb(tp[j].px & 0xFFFFu, (int)(tp[j].px >> 16), lane); }
                     }
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < kBatch; j++) {
-                if (j < nt && err == 0) { emit_token(q, lit, pos, tw[j], lane, err); }
+                if (j < nt && err == 0) { emit_token(q, lit, pos, tp[j].word, lane, err); }
             }
         }
         cursor = c2;
