@@ -215,28 +215,16 @@ void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
     }
 }
 
-// the whole encode on device buffers.  Indexed finder: sort -> match -> emit (the
-// greedy step runs inside the emit kernel, no token array); scan finder: scan -> emit.
+// the whole encode on device buffers: stage 1 (either finder) -> token words -> emit
 void run_encode(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
                 uint32_t window, uint32_t* tokens, uint32_t* counts, uint32_t* work_a,
                 uint32_t* work_m, uint64_t avg_block, uint8_t* d_out, const uint64_t* d_out_off,
                 uint64_t* d_out_bytes, int32_t* d_err, uint64_t prefix_acc, int prefix_fill,
                 hipStream_t st) {
-    if (finder == 0) {
-        run_stage1(0, d_in, d_in_off, n, window, tokens, counts, nullptr, nullptr, avg_block, st);
-        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
-        sqzk::launch_huffman_emit(tokens, d_in_off, counts, d_out, d_out_off, d_out_bytes, d_err, n,
-                                  prefix_acc, prefix_fill, st);
-    } else {
-        { SpanGuard g(st, SQZ_HIP_K_INDEX_SORT);
-          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, st); }
-        { SpanGuard g(st, SQZ_HIP_K_INDEX_MATCH);
-          sqzk::launch_index_match(d_in, d_in_off, n, window, work_a, work_m,
-                                   match_groups_for(avg_block), st); }
-        SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
-        sqzk::launch_huffman_emit_from_match(d_in, d_in_off, work_m, counts, d_out, d_out_off,
-                                             d_out_bytes, d_err, n, prefix_acc, prefix_fill, st);
-    }
+    run_stage1(finder, d_in, d_in_off, n, window, tokens, counts, work_a, work_m, avg_block, st);
+    SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
+    sqzk::launch_huffman_emit(tokens, d_in_off, counts, d_out, d_out_off, d_out_bytes, d_err, n,
+                              prefix_acc, prefix_fill, st);
 }
 
 // host-buffer encode of n blocks; prefix = pending header bits of block 0

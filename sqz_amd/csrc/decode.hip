@@ -43,7 +43,7 @@ __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& er
     int d = (int)(e >> 10);
     while (node >= (int)T::kRoot && node != (int)kNil) {           // deeper than 8 levels
         r.fill();
-        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 30);     // lo | hi << 10
+        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 32);     // lo | hi << 10
         node = (int)((kids >> (r.peek(1) ? 10 : 0)) & 0x3FFu);
         r.skip(1);
         if (++d > 2 * kStack) { node = (int)kNil; }

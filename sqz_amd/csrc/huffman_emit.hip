@@ -20,14 +20,16 @@
 
 namespace sqzk {
 
-constexpr int kTokStrip = 128;
-constexpr int kQueue = 64;           // fields per pack
-constexpr int kQueueRoom = 8;        // a token adds at most 6 fields (+2 for a 63-bit code)
+constexpr int kTokStrip = 128;        // token words staged in LDS per refill
+constexpr int kQueue = 32;            // fields of the one-at-a-time path per pack
+constexpr int kQueueRoom = 8;         // a token adds at most 6 fields (+2 for a 63-bit code)
+constexpr int kImageWords = 62;       // 64 lanes x <= 58 bits + carry
 
 struct EmitLds {
     EntropyLds entropy;
-    uint64_t   field[kQueue];        // width << 32 | value   (width 1..32)
-    uint64_t   image[kQueue / 2 + 2];// packed bits of one batch, stream order = MSB first
+    uint32_t   strip[kTokStrip];
+    uint64_t   field[kQueue];         // width << 32 | value   (width 1..32)
+    uint64_t   image[kImageWords];    // packed bits of one batch, stream order = MSB first
 };
 
 struct BitQueue {
@@ -76,16 +78,11 @@ struct BitQueue {
         else { bytes = capacity; error = kE2BIG; }
     }
 
-    // pack the queued fields behind the carried bits, store the full words
-    __device__ __forceinline__ void pack(int lane) {
-        if (count == 0) { return; }
-        uint32_t v = 0, n = 0;
-        if (lane < count) {
-            const uint64_t f = lds->field[lane];
-            v = (uint32_t)f;
-            n = (uint32_t)(f >> 32);
-        }
-        uint32_t incl = n;                                  // inclusive scan of the widths
+    // every lane contributes `n` bits (0..58, first-out bit = most significant of v):
+    // prefix sum of the widths, LDS atomic OR into the image behind the carried bits,
+    // full words leave for HBM
+    __device__ __forceinline__ void pack_lanes(uint64_t v, uint32_t n, int lane) {
+        uint32_t incl = n;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d);
@@ -93,7 +90,7 @@ struct BitQueue {
         }
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + (uint32_t)carry;
         if (n != 0) {
-            const uint32_t o = (uint32_t)carry + incl - n;  // first stream bit of this field
+            const uint32_t o = (uint32_t)carry + incl - n;  // first stream bit of this lane's bits
             const uint32_t w = o >> 6, s = o & 63u;
             if (s + n <= 64) {
                 atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
@@ -111,8 +108,20 @@ struct BitQueue {
         store_words(words, lane);
         const uint64_t rest = lds->image[words];           // partial word becomes the new carry
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane < kQueue / 2 + 2) { lds->image[lane] = (lane == 0) ? rest : 0ull; }
+        if (lane < kImageWords) { lds->image[lane] = (lane == 0) ? rest : 0ull; }
         carry = (int)(total & 63u);
+    }
+
+    // the queued fields of the one-at-a-time path (lane j = field j)
+    __device__ __forceinline__ void pack(int lane) {
+        if (count == 0) { return; }
+        uint32_t v = 0, n = 0;
+        if (lane < count) {
+            const uint64_t f = lds->field[lane];
+            v = (uint32_t)f;
+            n = (uint32_t)(f >> 32);
+        }
+        pack_lanes((uint64_t)v, n, lane);
         count = 0;
     }
 
@@ -177,62 +186,15 @@ __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& p
     if (lit.fault | pos.fault) { err = kE2BIG; }
 }
 
-// The token source: a 128-entry window of token words in two VGPRs (lane j holds
-// entries j and 64+j), refilled with coalesced loads; a word is fetched with
-// v_readlane -- no LDS round trip in front of every symbol.
-//   kFromMatch = false: entry k = token word k of stage 1 (any finder)
-//   kFromMatch = true : entry p = what starts at byte p according to the indexed
-//                       finder's match table (kTokMatch|len<<16|dist, or the byte);
-//                       the greedy step (squeeze.h:377-394) is the cursor advance
-// Offsets are 32-bit: a stream is at most 2^31 bytes (include/sqz/sqz.h).
-template <bool kFromMatch>
-struct TokenWindow {
-    const uint32_t* words;    // token words | match table
-    const uint8_t*  bytes_in; // input bytes (kFromMatch)
-    uint32_t total;           // tokens | bytes
-    uint32_t wbase;           // entry held by lane 0 of `cur`
-    uint32_t cur, nxt;
-
-    __device__ __forceinline__ uint32_t load(uint32_t at, int lane) const {
-        const uint32_t k = at + (uint32_t)lane;
-        if (k >= total) { return 0u; }
-        if (!kFromMatch) { return words[k]; }
-        const uint32_t m = (k + 2 < total) ? words[k] : 0u;          // last 2 bytes: literals
-        return m != 0 ? (kTokMatch | m) : (uint32_t)bytes_in[k];
-    }
-    __device__ __forceinline__ void open(uint32_t at, int lane) {
-        wbase = at;
-        cur = load(at, lane);
-        nxt = load(at + kWave, lane);
-    }
-    // once per step: afterwards entries [pos, pos+64) are in the window
-    __device__ __forceinline__ void cover(uint32_t pos, int lane) {
-        const uint32_t d = pos - wbase;
-        if (d >= 2 * kWave) { open(pos, lane); }
-        else if (d >= kWave) { cur = nxt; wbase += kWave; nxt = load(wbase + kWave, lane); }
-    }
-    __device__ __forceinline__ bool has(uint32_t pos) const { return pos - wbase < 2 * kWave; }
-    __device__ __forceinline__ uint32_t get(uint32_t pos) const {      // has(pos)
-        const uint32_t d = pos - wbase;
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d & 63u));
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)(d & 63u));
-        return d < kWave ? a : b;
-    }
-};
-
-// what one token needs on the way out: its symbols' ids and the extra-bit fields
-struct TokenPlan {
-    uint32_t word;
-    uint32_t lx, px;          // extra bits (value | width << 16) for length / distance
-};
-
-template <bool kFromMatch>
+// Tokens of stage 1 -> bit stream.  Up to 64 tokens per step, one per lane
+// (sqz_device.h: bump_lanes); a step shrinks to the tokens in front of the first
+// unseen symbol, halves when the no-restructure tests fail, and a single token that
+// still fails (= the tree really restructures) or needs the NYT escape goes through the
+// one-at-a-time path.
 __global__ __launch_bounds__(kWave)
-void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words | match table
-                         const uint64_t* __restrict__ tok_off,   // = in_off
-                         const uint32_t* __restrict__ tok_count, // unused when kFromMatch
-                         uint32_t* __restrict__ tok_count_out,   // kFromMatch: tokens per stream (or null)
-                         const uint8_t* __restrict__ in,         // input bytes (kFromMatch)
+void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
+                         const uint64_t* __restrict__ tok_off,
+                         const uint32_t* __restrict__ tok_count,
                          uint8_t* __restrict__ out,
                          const uint64_t* __restrict__ out_off,
                          uint64_t* __restrict__ out_bytes,
@@ -248,13 +210,14 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
     bind(lit, pos, &lds.entropy);
     lit.init_all(lane);
     pos.init_all(lane);
-    if (lane < kQueue / 2 + 2) {
+    if (lane < kImageWords) {
         // header bits that precede the payload (single-stream API): the carry
         lds.image[lane] = (lane == 0 && prefix_fill > 0) ? (prefix_acc << (64 - prefix_fill)) : 0ull;
     }
     __syncthreads();
 
-    const uint64_t t0 = uni64(tok_off[b]), t1 = uni64(tok_off[b + 1]);
+    const uint32_t* tok = tokens + uni64(tok_off[b]);
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
 
     BitQueue q;
     q.lds = &lds;
@@ -270,93 +233,68 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,    // token words 
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
-    TokenWindow<kFromMatch> win;
-    win.words = tokens + t0;
-    win.bytes_in = kFromMatch ? in + t0 : nullptr;
-    win.total = kFromMatch ? (uint32_t)(t1 - t0)
-                           : (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
-    win.open(0, lane);
-
     uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
     uint32_t* const freq = lds.entropy.lit_freq;
-    uint32_t cursor = 0, ntok = 0;
-    while (cursor < win.total && err == 0) {
-        win.cover(cursor, lane);
-        // ---- plan up to 4 symbols (whole tokens) ------------------------------------
-        TokenPlan tp[kBatch];
-        int s0 = kUnifiedDummy, s1 = kUnifiedDummy, s2 = kUnifiedDummy, s3 = kUnifiedDummy;
-        int nt = 0, ns = 0;
-        bool open_step = true;
-        uint32_t c2 = cursor;
-        auto put = [&](int leaf) {          // uniform selects keep the ids in SGPRs
-            s0 = ns == 0 ? leaf : s0;
-            s1 = ns == 1 ? leaf : s1;
-            s2 = ns == 2 ? leaf : s2;
-            s3 = ns == 3 ? leaf : s3;
-            ns++;
-        };
-#pragma unroll
-        for (int j = 0; j < kBatch; j++) {
-            tp[j].word = 0; tp[j].lx = 0; tp[j].px = 0;
-            if (open_step && c2 < win.total && ns < kBatch && win.has(c2)) {
-                const uint32_t t = win.get(c2);
-                if ((t & kTokMatch) == 0) {
-                    tp[j].word = t;
-                    nt = j + 1;
-                    put((int)(t & 0xFFu));
-                    c2 += 1;
-                } else if (ns + 2 <= kBatch) {
-                    const Code lc = len_code((int)((t >> 16) & 0x1FFu));          // squeeze.h:290-298
-                    const Code pc = pos_code((int)(t & 0x7FFFu));                 // squeeze.h:300-315
-                    tp[j].word = t;
-                    tp[j].lx = (uint32_t)lc.extra | ((uint32_t)lc.xbits << 16);
-                    tp[j].px = (uint32_t)pc.extra | ((uint32_t)pc.xbits << 16);
-                    nt = j + 1;
-                    put(kSymLen0 + lc.code);
-                    put(kLitNodes + pc.code);
-                    c2 += kFromMatch ? ((t >> 16) & 0x1FFu) : 1u;
-                } else {
-                    open_step = false;       // no room for this match: close the step
-                }
-            } else {
-                open_step = false;
-            }
+    uint32_t cursor = 0, sbase = 0, shave = 0;        // strip holds tokens [sbase, sbase+shave)
+    while (cursor < count && err == 0) {
+        if (cursor + kWave > sbase + shave && sbase + shave < count) {   // restage from the cursor
+            sbase = cursor;
+            const uint32_t left = count - sbase;
+            shave = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
+            for (uint32_t k = lane; k < shave; k += kWave) { lds.strip[k] = tok[sbase + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
-        // ---- all of them at once, if no link can change (sqz_device.h) ---------------
-        BatchOut bo;
-        bool done = false;
-        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63;
-        if (!frozen && ns > 1) {
-            done = bump_batch(link, freq, s0, s1, s2, s3, ns, lane, bo);
+        // ---- this lane's token ------------------------------------------------------
+        const uint32_t idx = cursor - sbase + (uint32_t)lane;
+        const bool valid = idx < shave;
+        const uint32_t t = valid ? lds.strip[idx] : 0u;
+        const bool is_match = (t & kTokMatch) != 0;
+        Code lc = {0, 0, 0}, pc = {0, 0, 0};
+        int a = (int)(t & 0xFFu), bsym = -1;
+        if (is_match) {
+            lc = len_code((int)((t >> 16) & 0x1FFu));                 // squeeze.h:290-298
+            pc = pos_code((int)(t & 0x7FFFu));                        // squeeze.h:300-315
+            a = kSymLen0 + lc.code;
+            bsym = kLitNodes + pc.code;
         }
-        if (done) {
-            uint64_t codes = bo.code_bits;
-            uint32_t depths = bo.depths;
-#pragma unroll
-            for (int j = 0; j < kBatch; j++) {
-                if (j < nt) {
-                    q.push32((uint32_t)codes & 0xFFFFu, (int)(depths & 0xFFu), lane);
-                    codes >>= 16; depths >>= 8;
-                    if (tp[j].word & kTokMatch) {
-                        if (tp[j].lx >> 16) { q.push_lsb(tp[j].lx & 0xFFFFu, (int)(tp[j].lx >> 16), lane); }
-                        q.push32((uint32_t)codes & 0xFFFFu, (int)(depths & 0xFFu), lane);
-                        codes >>= 16; depths >>= 8;
-                        if (tp[j].px >> 16) { q.push_lsb(tp[j].px & 0xFFFFu, (int)(tp[j].px >> 16), lane); }
-                    }
-                }
+        // unseen symbols need the NYT escape + an insert: they end the step
+        const uint32_t da = valid ? (uint32_t)(link[a] >> 52) & 0x3Fu : 1u;
+        const uint32_t db = (valid && is_match) ? (uint32_t)(link[bsym] >> 52) & 0x3Fu : 1u;
+        const uint64_t unseen = __ballot(valid && (da == 0 || db == 0));
+        const uint64_t vmask = __ballot(valid);
+        int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
+        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
+                            cursor > (1u << 24);
+        uint64_t ca = 0, cb = 0;
+        int wa = 0, wb = 0;
+        if (m >= 1 && !frozen) { m = bump_lanes(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
+        else { m = 0; }
+        const bool batched = m >= 1;
+        if (batched) {
+            // this lane's bits: code [extra] [code extra], first-out bit on top
+            uint64_t v = ca;
+            uint32_t n = (uint32_t)wa;
+            if (is_match) {
+                v = (v << lc.xbits) | (uint64_t)(lc.xbits ? (__brev((uint32_t)lc.extra) >> (32 - lc.xbits)) : 0u);
+                v = (v << wb) | cb;
+                v = (v << pc.xbits) | (uint64_t)(pc.xbits ? (__brev((uint32_t)pc.extra) >> (32 - pc.xbits)) : 0u);
+                n += (uint32_t)(lc.xbits + wb + pc.xbits);
             }
+            if (lane >= m) { n = 0; v = 0; }
+            if (__ballot(n > 58) != 0) { err = kE2BIG; }               // codes this long never occur
+            q.pack(lane);                                              // fields still queued go first
+            q.pack_lanes(v, n, lane);
+            cursor += (uint32_t)m;
         } else {
-#pragma unroll
-            for (int j = 0; j < kBatch; j++) {
-                if (j < nt && err == 0) { emit_token(q, lit, pos, tp[j].word, lane, err); }
-            }
+            // first token of the row, one symbol at a time (NYT escape / real restructure)
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            emit_token(q, lit, pos, t0, lane, err);
+            if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
+            cursor += 1;
         }
-        cursor = c2;
-        ntok += (uint32_t)nt;
-        if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
         if (q.error != 0) { err = q.error; }
+        if (lit.fault | pos.fault) { err = kE2BIG; }
     }
-    if (kFromMatch && lane == 0 && tok_count_out != nullptr) { tok_count_out[b] = ntok; }
 
     if (err == 0) { q.flush(lane); err = q.error; }
     else { q.pack(lane); }
@@ -372,20 +310,9 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          int32_t* err, uint32_t n_blocks,
                          uint64_t prefix_acc, int prefix_fill, hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(huffman_emit_kernel<false>, dim3(n_blocks), dim3(kWave), 0, stream,
-                       tokens, tok_off, tok_count, (uint32_t*)nullptr, (const uint8_t*)nullptr, out,
-                       out_off, out_bytes, err, n_blocks, prefix_acc, prefix_fill);
-}
-
-void launch_huffman_emit_from_match(const uint8_t* in, const uint64_t* in_off,
-                                    const uint32_t* match, uint32_t* tok_count_out, uint8_t* out,
-                                    const uint64_t* out_off, uint64_t* out_bytes,
-                                    int32_t* err, uint32_t n_blocks,
-                                    uint64_t prefix_acc, int prefix_fill, hipStream_t stream) {
-    if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(huffman_emit_kernel<true>, dim3(n_blocks), dim3(kWave), 0, stream,
-                       match, in_off, (const uint32_t*)nullptr, tok_count_out, in, out, out_off,
-                       out_bytes, err, n_blocks, prefix_acc, prefix_fill);
+    hipLaunchKernelGGL(huffman_emit_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
+                       tokens, tok_off, tok_count, out, out_off, out_bytes, err, n_blocks,
+                       prefix_acc, prefix_fill);
 }
 
 } // namespace sqzk

@@ -224,8 +224,8 @@ struct BitSource {
 //    lanes then do in one step.  Any flag -> the slow path runs instead, from
 //    the untouched state, so the result is the reference's in both cases.
 //
-// A node's links are one 64-bit word: up | up2 | up3 | lo | hi (10 bits each,
-// 0x3FF = none) | depth (6 bits).  up2 / up3 (grandparent, great-grandparent)
+// A node's links are one 64-bit word: low dword up | up2 | up3, high dword
+// lo | hi (10 bits each, 0x3FF = none) | depth (6 bits).  up2 / up3 (grandparent, great-grandparent)
 // exist only to shorten the leaf->root walk of the fast path to one dependent
 // LDS read per three levels; the slow path maintains them wherever it moves a
 // subtree (relabel), and never reads them.
@@ -239,7 +239,7 @@ struct Node {                        // unpacked view of a link word
 
 __device__ __forceinline__ Node unpack(uint64_t w) {
     Node n;
-    const uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 30);
+    const uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
     n.up = a & 0x3FFu; n.up2 = (a >> 10) & 0x3FFu; n.up3 = (a >> 20) & 0x3FFu;
     n.lo = b & 0x3FFu; n.hi = (b >> 10) & 0x3FFu; n.bits = (b >> 20) & 0x3Fu;
     return n;
@@ -247,10 +247,10 @@ __device__ __forceinline__ Node unpack(uint64_t w) {
 
 __device__ __forceinline__ uint64_t pack(const Node& n) {
     return (uint64_t)(n.up | (n.up2 << 10) | (n.up3 << 20)) |
-           ((uint64_t)(n.lo | (n.hi << 10) | (n.bits << 20)) << 30);
+           ((uint64_t)(n.lo | (n.hi << 10) | (n.bits << 20)) << 32);
 }
 
-constexpr uint64_t kEmptyLinks = 0x3FFFFFFFull | (0xFFFFFull << 30);   // all nil, depth 0
+constexpr uint64_t kEmptyLinks = 0x3FFFFFFFull | (0xFFFFFull << 32);   // all nil, depth 0
 
 // shared per-wave scratch for both trees
 struct TreeScratch {
@@ -526,7 +526,7 @@ struct Tree {
         // the leaf's own word gives its depth, so the walk has a known trip count:
         // one dependent read per three levels, no end-of-chain tests inside
         const uint64_t w0 = uni64(link[s]);
-        const int levels = (int)((uint32_t)(w0 >> 50) & 0x3Fu);
+        const int levels = (int)((uint32_t)(w0 >> 52) & 0x3Fu);
         const int stop = levels < kMaxFastDepth ? levels : kMaxFastDepth;
         uint32_t w = (uint32_t)w0;
         int mine = (lane == 0) ? s : (int)kNil;
@@ -613,7 +613,7 @@ __device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut,
         const int idx = lane + 64 * j;
         int node = T::kRoot, used = 0;
         for (int level = 0; level < 8; level++) {
-            const uint32_t kids = (uint32_t)(link[node] >> 30);
+            const uint32_t kids = (uint32_t)(link[node] >> 32);
             const int bit = (idx >> (7 - level)) & 1;
             const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
             used = level + 1;
@@ -686,7 +686,7 @@ __device__ __forceinline__ bool bump_batch(uint64_t* link, uint32_t* freq,
     leaf = live ? leaf : kUnifiedDummy;
     const int base = leaf >= kLitNodes ? kLitNodes : 0;
     const uint64_t w0 = link[leaf];
-    const int depth = (int)((uint32_t)(w0 >> 50) & 0x3Fu);
+    const int depth = (int)((uint32_t)(w0 >> 52) & 0x3Fu);
     const bool bad = live & (depth == 0 || depth > kBatchDepth);     // unseen / too deep
     uint32_t w = (uint32_t)w0;
     int mine = (l == 0) ? (leaf - base) : (int)kNil;                   // ids local to the tree
@@ -731,6 +731,86 @@ __device__ __forceinline__ bool bump_batch(uint64_t* link, uint32_t* freq,
     const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane(depth, 48);
     out.depths = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
     return true;
+}
+
+// ---------------------------------------------------------------------------
+// Up to 64 tokens per step: lane = token (its lit-tree symbol, then, for a back
+// reference, its pos-tree symbol); every lane walks its own leaf->root chains.
+// Same exactness argument as bump_batch above.  n(c) is counted in the top 7 bits
+// of the count word with LDS atomic adds whose return value tells a lane how many
+// lanes were counted at c before it (its rank r).  A lane is `bad` if, at some node
+// of its chains, f0(c) + r + 1 would break one of the three tests.  Take the
+// tokens in front of the first bad lane: for every node at most `allowed` of them
+// pass through it (they all have rank < allowed), so the tests hold for that prefix
+// whatever order the hardware serialises same-address atomics in -- a different
+// order can only shorten the prefix.  Two sweeps over the chains:
+//   1. count + test + read the code off the chain
+//   2. prefix lanes: count += 1, n -= 1; the others: n -= 1
+// Batching stops once a root count nears 2^25 (the serial path has no such limit).
+constexpr uint32_t kCntShift = 25;
+constexpr uint32_t kCntOne = 1u << kCntShift;
+constexpr uint32_t kCountMask = kCntOne - 1u;
+
+__device__ __forceinline__ void lanes_add(const uint64_t* link, uint32_t* freq, int leaf, uint32_t delta) {
+    if (leaf < 0) { return; }
+    const int base = leaf >= kLitNodes ? kLitNodes : 0;
+    uint32_t c = (uint32_t)(leaf - base);
+    while (c != kNil) {
+        atomicAdd(&freq[base + (int)c], delta);
+        c = reinterpret_cast<const uint32_t*>(link)[2 * (base + (int)c)] & 0x3FFu;
+    }
+}
+
+// sweep 1 for one symbol of this lane; returns true when the lane is bad
+__device__ __forceinline__ bool lanes_count(const uint64_t* link, uint32_t* freq, int leaf,
+                                            uint64_t& code, int& depth) {
+    code = 0; depth = 0;
+    if (leaf < 0) { return false; }
+    const int base = leaf >= kLitNodes ? kLitNodes : 0;
+    uint32_t c = (uint32_t)(leaf - base);
+    uint32_t p = (uint32_t)link[base + (int)c] & 0x3FFu;
+    bool bad = false, prev_hi = false;
+    uint32_t prev_reach = 0;
+    int k = 0;
+    for (;;) {
+        const uint32_t old = atomicAdd(&freq[base + (int)c], kCntOne);
+        if (p == kNil) { break; }                                        // the root: counted, no test
+        const uint32_t f0c = old & kCountMask;
+        const uint32_t reach = f0c + (old >> kCntShift) + 1u;            // my count of c after my add
+        const uint64_t wp = link[base + (int)p];
+        const uint32_t kids = (uint32_t)(wp >> 32);
+        const uint32_t lo = kids & 0x3FFu, hi = (kids >> 10) & 0x3FFu;
+        const bool is_hi = (hi == c);
+        const uint32_t sib = is_hi ? lo : hi;
+        const bool has_sib = sib != kNil;
+        const uint32_t f0s = freq[base + (int)(has_sib ? sib : p)] & kCountMask;
+        bad |= has_sib & (is_hi ? (f0s > f0c + 1u) : (reach > f0s));     // swap tests
+        bad |= prev_hi & has_sib & (prev_reach > f0s);                   // promote test of the level below
+        code |= (uint64_t)(is_hi ? 1u : 0u) << k;
+        k++;
+        prev_hi = is_hi; prev_reach = reach;
+        c = p;
+        p = (uint32_t)wp & 0x3FFu;
+        if (k >= 48) { bad = true; }                                     // never: left to the serial path
+    }
+    depth = k;
+    return bad;
+}
+
+// Whole wave: lanes [0, m) offer their symbols (a, then b; unified leaf ids, -1 = none).
+// Returns how many leading tokens were applied (0..m); codes/depths are valid for those.
+__device__ __forceinline__ int bump_lanes(uint64_t* link, uint32_t* freq, int lane, int m, int a, int b,
+                                          uint64_t& code_a, int& depth_a, uint64_t& code_b, int& depth_b) {
+    const bool take = lane < m;
+    const int la = take ? a : -1, lb = take ? b : -1;
+    bool bad = lanes_count(link, freq, la, code_a, depth_a);
+    bad |= lanes_count(link, freq, lb, code_b, depth_b);
+    const uint64_t bm = __ballot(bad);
+    const int ok = bm != 0 ? __builtin_ctzll(bm) : m;                    // tokens in front of the first bad lane
+    const uint32_t delta = lane < ok ? (1u - kCntOne) : (0u - kCntOne);
+    lanes_add(link, freq, la, delta);
+    lanes_add(link, freq, lb, delta);
+    return ok < m ? ok : m;
 }
 
 __device__ __forceinline__ void bind(LitTree& lit, PosTree& pos, EntropyLds* s) {

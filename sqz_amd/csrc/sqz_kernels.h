@@ -34,14 +34,6 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          int32_t* err, uint32_t n_blocks,
                          uint64_t prefix_acc, int prefix_fill, hipStream_t stream);
 
-// stage 2 fed by the indexed finder's match table directly (greedy step inside):
-// saves the token array round trip and the parse kernel
-void launch_huffman_emit_from_match(const uint8_t* in, const uint64_t* in_off,
-                                    const uint32_t* match, uint32_t* tok_count_out, uint8_t* out,
-                                    const uint64_t* out_off, uint64_t* out_bytes,
-                                    int32_t* err, uint32_t n_blocks,
-                                    uint64_t prefix_acc, int prefix_fill, hipStream_t stream);
-
 // decode (squeeze.h:502-551): entropy stage -> token words -> LZ77 expansion.
 // tokens: one uint32 slot per OUTPUT byte, addressed by out_off; tok_count[n].
 void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
