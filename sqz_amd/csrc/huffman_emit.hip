@@ -267,10 +267,10 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                             cursor > (1u << 24);
         uint64_t ca = 0, cb = 0;
         int wa = 0, wb = 0;
+        const int offered = m;
         if (m >= 1 && !frozen) { m = bump_lanes(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
         else { m = 0; }
-        const bool batched = m >= 1;
-        if (batched) {
+        if (m >= 1) {
             // this lane's bits: code [extra] [code extra], first-out bit on top
             uint64_t v = ca;
             uint32_t n = (uint32_t)wa;
@@ -285,10 +285,12 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             q.pack(lane);                                              // fields still queued go first
             q.pack_lanes(v, n, lane);
             cursor += (uint32_t)m;
-        } else {
-            // first token of the row, one symbol at a time (NYT escape / real restructure)
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-            emit_token(q, lit, pos, t0, lane, err);
+        }
+        if (m < offered || offered == 0 || frozen) {
+            // the token the step stopped at (NYT escape / the tree restructures / frozen tree):
+            // one symbol at a time, always exact
+            const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)t, m);
+            emit_token(q, lit, pos, tx, lane, err);
             if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
             cursor += 1;
         }
