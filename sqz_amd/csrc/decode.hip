@@ -55,6 +55,32 @@ __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& er
     return node;
 }
 
+// one symbol through the lookup table WITHOUT touching the tree (the tree is static
+// while a step is being read ahead); -1 = ran past the readable bits / missing child
+template <class T>
+__device__ __forceinline__ int peek_symbol(BitSource& r, const T& t) {
+    r.fill();
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(8)]);
+    int node = (int)(e & 0x3FFu);
+    r.skip((int)(e >> 10));
+    int d = (int)(e >> 10);
+    while (node >= (int)T::kRoot && node != (int)kNil) {           // deeper than 8 levels
+        r.fill();
+        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 32);
+        node = (int)((kids >> (r.peek(1) ? 10 : 0)) & 0x3FFu);
+        r.skip(1);
+        if (++d > 2 * kStack) { node = (int)kNil; }
+    }
+    if (r.overrun() || node == (int)kNil) { return -1; }
+    return node;
+}
+
+// Up to 64 tokens per step (sqz_device.h: bump_lanes): the tokens are first read ahead
+// with both trees held still -- valid as long as no link changes, which is exactly what
+// bump_lanes then establishes for a prefix of them; the token the step stops at (NYT
+// escape, a restructuring update, malformed input) is decoded again by the
+// one-at-a-time path from its own bit position, so errors and updates are the
+// reference's.
 __global__ __launch_bounds__(kWave)
 void entropy_decode_kernel(const uint8_t* __restrict__ in,
                            const uint64_t* __restrict__ in_off,
@@ -84,23 +110,29 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
 
     BitSource r;
     const uint64_t i0 = uni64(in_off[b]), i1 = uni64(in_off[b + 1]);
-    r.open(in + i0, i1 - i0, start_bit);
+    const uint8_t* const src = in + i0;
+    const uint64_t src_bytes = i1 - i0;
+    r.open(src, src_bytes, start_bit, lane);
     int err = 0;
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
+    uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
+    uint32_t* const freq = lds.entropy.lit_freq;
     uint64_t i = 0;
-    uint32_t ntok = 0, tok_reg = 0;
-    while (i < bytes && err == 0) {
+    uint32_t ntok = 0;
+
+    // squeeze.h:509-549 for exactly one token, with every check and the tree updates
+    auto decode_one = [&]() {
         int s = read_symbol(r, lit, lane, err);
-        if (err != 0) { break; }
+        if (err != 0) { return; }
         if (s == kLitNyt) {                                            // squeeze.h:512-520
             s = (int)r.get_lsb(9);
-            if (r.overrun()) { err = kE2BIG; break; }
-            if (s == 256 || s >= kLitNyt) { err = kEINVAL; break; }
+            if (r.overrun()) { err = kE2BIG; return; }
+            if (s == 256 || s >= kLitNyt) { err = kEINVAL; return; }
             const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit.up_of(s));
-            if (up != kNil) { err = kEINVAL; break; }
-            if (!lit.insert_wave(s, lane)) { err = kE2BIG; break; }
+            if (up != kNil) { err = kEINVAL; return; }
+            if (!lit.insert_wave(s, lane)) { err = kE2BIG; return; }
         }
         uint32_t word;
         if (s <= 0xFF) {
@@ -112,35 +144,98 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             int len = base;
             if (xb != 0) {
                 len += (int)r.get_lsb(xb);
-                if (r.overrun()) { err = kE2BIG; break; }
+                if (r.overrun()) { err = kE2BIG; return; }
             }
-            if (len < kLenMin || len > kLenMax) { err = kEINVAL; break; }
+            if (len < kLenMin || len > kLenMax) { err = kEINVAL; return; }
             int pk = read_symbol(r, pos, lane, err);                   // squeeze.h:476-500
-            if (err != 0) { break; }
+            if (err != 0) { return; }
             if (pk == kPosNyt) {
                 pk = (int)r.get_lsb(5);
-                if (r.overrun()) { err = kE2BIG; break; }
-                if (pk >= kPosNyt) { err = kEINVAL; break; }
+                if (r.overrun()) { err = kE2BIG; return; }
+                if (pk >= kPosNyt) { err = kEINVAL; return; }
                 const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos.up_of(pk));
-                if (up != kNil) { err = kEINVAL; break; }
-                if (!pos.insert_wave(pk, lane)) { err = kE2BIG; break; }
+                if (up != kNil) { err = kEINVAL; return; }
+                if (!pos.insert_wave(pk, lane)) { err = kE2BIG; return; }
             }
             pos_base_of(pk, base, xb);
             int dist = base;
             if (xb != 0) {
                 dist += (int)r.get_lsb(xb);
-                if (r.overrun()) { err = kE2BIG; break; }
+                if (r.overrun()) { err = kE2BIG; return; }
             }
-            if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; break; }
+            if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; return; }
             word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
             i += (uint64_t)len;
         }
-        if (lit.fault | pos.fault) { err = kE2BIG; break; }
-        if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
+        if (lit.fault | pos.fault) { err = kE2BIG; return; }
+        if (lane == 0) { tok[ntok] = word; }
         ntok++;
-        if ((ntok & 63u) == 0) { tok[ntok - 64 + lane] = tok_reg; }
+    };
+
+    while (i < bytes && err == 0) {
+        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
+                            ntok > (1u << 24);
+        if (lit.lut_ok == 0) { lit.build_lut(lane); }
+        if (pos.lut_ok == 0) { pos.build_lut(lane); }
+        // ---- read ahead: up to 64 tokens with the trees held still --------------------
+        const uint64_t bit0 = r.pos;
+        uint32_t word_v = 0;            // lane j: token j of this step
+        uint32_t after_v = 0;           // lane j: bits consumed << 16 | bytes produced, after token j
+        int a_v = -1, b_v = -1;         // lane j: its symbols (unified leaf ids)
+        int m = 0;
+        uint64_t ii = i;
+        while (m < kWave && ii < bytes && !frozen) {
+            const int s = peek_symbol(r, lit);
+            if (s < 0 || s == kLitNyt) { break; }
+            uint32_t word;
+            int sb = -1;
+            if (s <= 0xFF) {
+                word = (uint32_t)s;
+                ii += 1;
+            } else {
+                int base, xb;
+                len_base_of(s - kSymLen0, base, xb);
+                int len = base;
+                if (xb != 0) { len += (int)r.get_lsb(xb); }
+                const int pk = peek_symbol(r, pos);
+                if (pk < 0 || pk == kPosNyt || len > kLenMax) { break; }
+                pos_base_of(pk, base, xb);
+                int dist = base;
+                if (xb != 0) { dist += (int)r.get_lsb(xb); }
+                if (r.overrun() || (uint64_t)dist > ii || (uint64_t)len > bytes - ii) { break; }
+                word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
+                sb = kLitNodes + pk;
+                ii += (uint64_t)len;
+            }
+            const bool me = lane == m;
+            word_v = me ? word : word_v;
+            a_v = me ? s : a_v;
+            b_v = me ? sb : b_v;
+            after_v = me ? (((uint32_t)(r.pos - bit0) << 16) | (uint32_t)(ii - i)) : after_v;
+            m++;
+        }
+        // ---- apply the longest prefix that changes no link ------------------------------
+        uint64_t ca, cb;
+        int wa, wb;
+        int done = 0;
+        bool reopen = false;
+        uint64_t reopen_at = 0;
+        if (m > 0) { done = bump_lanes(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        if (done > 0) {
+            if (lane < done) { tok[ntok + (uint32_t)lane] = word_v; }
+            const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)after_v, done - 1);
+            ntok += (uint32_t)done;
+            i += (uint64_t)(af & 0xFFFFu);
+            reopen_at = bit0 + (uint64_t)(af >> 16);
+            reopen = done < m || (m < kWave && i < bytes);
+        } else if (!frozen) {
+            reopen_at = bit0;
+            reopen = true;
+        }
+        if (reopen) { r.seek(reopen_at); }
+        // ---- whatever stopped the step: one token, exactly ----------------------------------
+        if (i < bytes && (done < m || m < kWave)) { decode_one(); }
     }
-    if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
     if (lane == 0) {
         tok_count[b] = ntok;
         err_out[b] = err;

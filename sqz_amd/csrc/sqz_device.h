@@ -144,48 +144,66 @@ struct BitSink {
 // first; the reference fetches it in 8-byte big-endian groups and fails with
 // E2BIG when a group is incomplete (:72-80), so only the first limit/8*8 bytes
 // are readable.  Driven wave-uniformly: `acc` keeps the next `valid` (>= 32
-// after fill()) bits left-aligned, refilled 32 bits at a time with the following
-// dword already in flight.  Bits past the readable end read as zero and raise
-// E2BIG once they are CONSUMED (checked by the caller per symbol).
+// after fill()) bits left-aligned.  The stream itself sits in two VGPR rows
+// (lane j = dword wbase+j / wbase+64+j, already big-endian), loaded with one
+// coalesced vector load per 2048 bits and picked with v_readlane, so no memory
+// latency (and no scalar-load wait mixed into the LDS waits) sits between two
+// symbols.  Bits past the readable end read as zero and raise E2BIG once they
+// are CONSUMED (checked by the caller per symbol).
 struct BitSource {
     const uint8_t* in;
     uint64_t readable;   // bits
     uint64_t pos;        // bits consumed
     uint64_t acc;
     int      valid;      // bits in acc
-    uint32_t ahead;      // the dword after the ones already in acc (raw, as loaded)
+    uint32_t next_dw;    // dword index that follows the bits in acc
+    uint32_t wbase;      // dword index held by lane 0 of `cur`
+    uint32_t cur, nxt;   // VGPR rows
+    int      lane;
     int      error;
 
-    // raw little-endian dword at stream bit `bit_at` (multiple of 32); zero past the end.
-    // Kept raw so that nothing waits for the load before the next fill() needs it.
-    __device__ __forceinline__ uint32_t fetch_raw(uint64_t bit_at) const {
-        if (bit_at + 32 <= readable) {
-            return *reinterpret_cast<const uint32_t*>(in + (bit_at >> 3));
+    __device__ __forceinline__ uint32_t load_row(uint32_t dw0) const {
+        const uint64_t k = (uint64_t)dw0 + (uint32_t)lane;
+        if (k * 32 + 32 <= readable) {
+            return __builtin_bswap32(reinterpret_cast<const uint32_t*>(in)[k]);
         }
         return 0u;
     }
-    __device__ __forceinline__ static uint32_t be(uint32_t raw) {
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bswap32(raw));
+    __device__ __forceinline__ uint32_t dword_at(uint32_t k) {
+        uint32_t d = k - wbase;
+        if (d >= 2 * kWave) {                           // outside both rows (also: behind them)
+            wbase = k; cur = load_row(k); nxt = load_row(k + kWave); d = 0;
+        } else if (d >= kWave) {
+            cur = nxt; wbase += kWave; nxt = load_row(wbase + kWave); d -= kWave;
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)d);
     }
-
-    __device__ __forceinline__ void open(const uint8_t* p, uint64_t limit_bytes, uint64_t start_bit) {
+    __device__ __forceinline__ void seek(uint64_t bit) {
+        pos = bit;
+        const uint32_t k = (uint32_t)(bit >> 5);
+        const int sh = (int)(bit & 31u);
+        const uint64_t hi = dword_at(k), lo = dword_at(k + 1);
+        acc = ((hi << 32) | lo) << sh;
+        valid = 64 - sh;
+        next_dw = k + 2;
+    }
+    __device__ __forceinline__ void open(const uint8_t* p, uint64_t limit_bytes, uint64_t start_bit, int lane_) {
         in = p;
+        lane = lane_;
         readable = (limit_bytes / 8) * 64;
         error = 0;
-        const uint64_t w = start_bit & ~(uint64_t)31;
-        pos = start_bit;
-        acc = ((uint64_t)be(fetch_raw(w)) << 32) | (uint64_t)be(fetch_raw(w + 32));
-        valid = 64 - (int)(start_bit - w);
-        acc <<= (start_bit - w);
-        ahead = fetch_raw(w + 64);
+        wbase = (uint32_t)(start_bit >> 5);
+        cur = load_row(wbase);
+        nxt = load_row(wbase + kWave);
+        seek(start_bit);
     }
 
     // make at least 32 bits available
     __device__ __forceinline__ void fill() {
         if (valid < 32) {
-            acc |= (uint64_t)be(ahead) << (32 - valid);
+            acc |= (uint64_t)dword_at(next_dw) << (32 - valid);
             valid += 32;
-            ahead = fetch_raw(pos + (uint64_t)valid);    // in flight until the next fill
+            next_dw++;
         }
     }
 
