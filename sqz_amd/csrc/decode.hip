@@ -24,9 +24,13 @@
 
 namespace sqzk {
 
+constexpr int kStageDw = 128;          // staged stream dwords (big-endian values): 4096 bits
+
 struct DecodeLds {
     EntropyLds entropy;
     DecodeLuts luts;
+    uint32_t   stage[kStageDw];
+    uint2      slot[kWave];             // read-ahead tokens: word, bits used
 };
 
 // squeeze.h:429-442; returns the leaf or -1 with err set.  The first 8 levels
@@ -37,7 +41,7 @@ template <class T>
 __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& err) {
     if (t.lut_ok == 0) { t.build_lut(lane); }
     r.fill();
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(8)]);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(T::kLutBits)]);
     int node = (int)(e & 0x3FFu);
     r.skip((int)(e >> 10));
     int d = (int)(e >> 10);
@@ -60,7 +64,7 @@ __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& er
 template <class T>
 __device__ __forceinline__ int peek_symbol(BitSource& r, const T& t) {
     r.fill();
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(8)]);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lut[r.peek(T::kLutBits)]);
     int node = (int)(e & 0x3FFu);
     r.skip((int)(e >> 10));
     int d = (int)(e >> 10);
@@ -172,69 +176,142 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         ntok++;
     };
 
+    uint32_t sdw = 0xFFFFFFFFu;                      // stream dword held by stage[0] (none yet)
     while (i < bytes && err == 0) {
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
                             ntok > (1u << 24);
         if (lit.lut_ok == 0) { lit.build_lut(lane); }
         if (pos.lut_ok == 0) { pos.build_lut(lane); }
-        // ---- read ahead: up to 64 tokens with the trees held still --------------------
+        // ---- read ahead with the trees held still: every lane decodes the token that would
+        //      start at ITS bit offset, then the real starts are picked by following the
+        //      lengths from the known start (64 offsets per round, up to 64 tokens) ----------
         const uint64_t bit0 = r.pos;
-        uint32_t word_v = 0;            // lane j: token j of this step
-        uint32_t after_v = 0;           // lane j: bits consumed << 16 | bytes produced, after token j
-        int a_v = -1, b_v = -1;         // lane j: its symbols (unified leaf ids)
+        uint64_t base = bit0;
         int m = 0;
-        uint64_t ii = i;
-        while (m < kWave && ii < bytes && !frozen) {
-            const int s = peek_symbol(r, lit);
-            if (s < 0 || s == kLitNyt) { break; }
-            uint32_t word;
-            int sb = -1;
-            if (s <= 0xFF) {
-                word = (uint32_t)s;
-                ii += 1;
-            } else {
-                int base, xb;
-                len_base_of(s - kSymLen0, base, xb);
-                int len = base;
-                if (xb != 0) { len += (int)r.get_lsb(xb); }
-                const int pk = peek_symbol(r, pos);
-                if (pk < 0 || pk == kPosNyt || len > kLenMax) { break; }
-                pos_base_of(pk, base, xb);
-                int dist = base;
-                if (xb != 0) { dist += (int)r.get_lsb(xb); }
-                if (r.overrun() || (uint64_t)dist > ii || (uint64_t)len > bytes - ii) { break; }
-                word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
-                sb = kLitNodes + pk;
-                ii += (uint64_t)len;
+        bool stop = frozen;
+        int myslot = -1;
+        uint32_t my_word = 0, my_used = 0;
+        while (m < kWave && !stop) {
+            const uint32_t k0 = (uint32_t)(base >> 5);
+            if (k0 < sdw || ((uint32_t)((base + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
+                sdw = k0;
+#pragma unroll
+                for (int h = 0; h < kStageDw / kWave; h++) {
+                    const uint64_t k = (uint64_t)sdw + (uint32_t)(h * kWave + lane);
+                    uint32_t v = 0;
+                    if (k * 32 + 32 <= r.readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
+                    lds.stage[h * kWave + lane] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
-            const bool me = lane == m;
-            word_v = me ? word : word_v;
-            a_v = me ? s : a_v;
-            b_v = me ? sb : b_v;
-            after_v = me ? (((uint32_t)(r.pos - bit0) << 16) | (uint32_t)(ii - i)) : after_v;
-            m++;
+            // this lane's 64 stream bits from its offset
+            const uint64_t o = base + (uint32_t)lane;
+            const uint32_t k = (uint32_t)(o >> 5) - sdw;
+            const int sh = (int)(o & 31u);
+            const uint32_t d0 = lds.stage[k], d1 = lds.stage[k + 1], d2 = lds.stage[k + 2];
+            uint64_t w = ((((uint64_t)d0 << 32) | d1) << sh) | (sh ? ((uint64_t)d2 >> (32 - sh)) : 0ull);
+            // literal / length symbol
+            uint32_t e = lds.luts.lit[(uint32_t)(w >> 56)];
+            uint32_t node = e & 0x3FFu;
+            uint32_t used = e >> 10;
+            w <<= used;
+            for (int it = 0; it < 56; it++) {                      // deeper than the table
+                const bool more = node >= (uint32_t)kLitLeaves && node != kNil;
+                if (__ballot(more) == 0) { break; }
+                if (more) {
+                    const uint32_t kids = (uint32_t)(link[node] >> 32);
+                    node = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
+                    w <<= 1;
+                    used++;
+                }
+            }
+            bool bad = node >= (uint32_t)kLitLeaves;              // nil / still inside
+            bool esc = node == (uint32_t)kLitNyt;
+            uint32_t word = node;
+            if (!bad && !esc && node > 0xFFu) {                    // squeeze.h:458-500, read only
+                int bs, xb;
+                len_base_of((int)node - kSymLen0, bs, xb);
+                uint32_t len = (uint32_t)bs;
+                if (xb) { len += __brev((uint32_t)(w >> (64 - xb))) >> (32 - xb); }
+                w <<= xb; used += (uint32_t)xb;
+                const uint32_t e2 = lds.luts.pos[(uint32_t)(w >> (64 - PosTree::kLutBits))];
+                uint32_t n2 = e2 & 0x3FFu;
+                w <<= (e2 >> 10); used += (e2 >> 10);
+                for (int it = 0; it < 56; it++) {
+                    if (!(n2 >= (uint32_t)kPosLeaves && n2 != kNil)) { break; }
+                    const uint32_t kids = (uint32_t)(link[kLitNodes + (int)n2] >> 32);
+                    n2 = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
+                    w <<= 1;
+                    used++;
+                }
+                bad |= n2 >= (uint32_t)kPosLeaves;
+                esc |= n2 == (uint32_t)kPosNyt;
+                if (!bad && !esc) {
+                    pos_base_of((int)n2, bs, xb);
+                    uint32_t dist = (uint32_t)bs;
+                    if (xb) { dist += __brev((uint32_t)(w >> (64 - xb))) >> (32 - xb); }
+                    used += (uint32_t)xb;
+                    bad |= len > (uint32_t)kLenMax;
+                    word = kTokMatch | (len << 16) | dist;
+                }
+            }
+            const bool ok = !bad && !esc && used <= 64u && o + used <= r.readable;
+            const uint64_t okmask = __ballot(ok);
+            // follow the token lengths from offset 0 of this round
+            uint32_t s = 0;
+            while (s < (uint32_t)kWave && m < kWave) {
+                if (((okmask >> s) & 1ull) == 0) { stop = true; break; }
+                if ((uint32_t)lane == s) { myslot = m; my_word = word; my_used = used; }
+                s += (uint32_t)__builtin_amdgcn_readlane((int)used, (int)s);
+                m++;
+            }
+            base += s;
+            // hand this round's picks to the slots (a lane may be picked again next round)
+            if (myslot >= 0) { lds.slot[myslot] = make_uint2(my_word, my_used); myslot = -1; }
         }
-        // ---- apply the longest prefix that changes no link ------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // ---- lane j = token j: positions, validity, symbols ---------------------------------
+        uint32_t word_v = 0, used_v = 0;
+        if (lane < m) { const uint2 sl = lds.slot[lane]; word_v = sl.x; used_v = sl.y; }
+        const bool is_match = (word_v & kTokMatch) != 0;
+        const uint32_t tlen_v = lane < m ? (is_match ? ((word_v >> 16) & 0x1FFu) : 1u) : 0u;
+        uint32_t scan = (used_v << 16) | tlen_v;               // both sums fit 16 bits
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = __shfl_up(scan, d);
+            if (lane >= d) { scan += up; }
+        }
+        const uint64_t out_before = i + (uint64_t)((scan & 0xFFFFu) - tlen_v);
+        const bool invalid = lane < m &&
+            (out_before >= bytes ||
+             (is_match && ((uint64_t)(word_v & 0x7FFFu) > out_before || (uint64_t)tlen_v > bytes - out_before)));
+        const uint64_t inv = __ballot(invalid);
+        if (inv != 0) { const int f = __builtin_ctzll(inv); m = f < m ? f : m; }
+        int a_v = -1, b_v = -1;
+        if (lane < m) {
+            if (is_match) {
+                a_v = kSymLen0 + len_code((int)tlen_v).code;
+                b_v = kLitNodes + pos_code((int)(word_v & 0x7FFFu)).code;
+            } else {
+                a_v = (int)word_v;
+            }
+        }
+        // ---- apply the longest prefix that changes no link ------------------------------------
         uint64_t ca, cb;
         int wa, wb;
         int done = 0;
-        bool reopen = false;
-        uint64_t reopen_at = 0;
         if (m > 0) { done = bump_lanes(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        uint64_t resume = bit0;
         if (done > 0) {
             if (lane < done) { tok[ntok + (uint32_t)lane] = word_v; }
-            const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)after_v, done - 1);
+            const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)scan, done - 1);
             ntok += (uint32_t)done;
             i += (uint64_t)(af & 0xFFFFu);
-            reopen_at = bit0 + (uint64_t)(af >> 16);
-            reopen = done < m || (m < kWave && i < bytes);
-        } else if (!frozen) {
-            reopen_at = bit0;
-            reopen = true;
+            resume = bit0 + (uint64_t)(af >> 16);
         }
-        if (reopen) { r.seek(reopen_at); }
-        // ---- whatever stopped the step: one token, exactly ----------------------------------
-        if (i < bytes && (done < m || m < kWave)) { decode_one(); }
+        r.seek(resume);
+        // ---- whatever stopped the step: one token, exactly ------------------------------------
+        if (i < bytes && done < kWave) { decode_one(); }
     }
     if (lane == 0) {
         tok_count[b] = ntok;

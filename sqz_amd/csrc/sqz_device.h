@@ -313,13 +313,13 @@ __device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut,
 
 // REF_LEAVES is the reference's leaf count n (512 / 32, squeeze.h:204-205): it
 // only fixes how many leaf splits huffman_insert allows (n - 2, huffman.h:180).
-template <int LEAVES, int NODES, int REF_LEAVES>
+template <int LEAVES, int NODES, int REF_LEAVES, int LUT_BITS>
 struct Tree {
     // LDS storage
     uint64_t* link;
     uint32_t* freq;
     TreeScratch* scratch;
-    uint16_t* lut;      // decoder only: 256 entries, node | bits used << 10
+    uint16_t* lut;      // decoder only: 2^kLutBits entries, node | bits used << 10
     // wave-uniform registers
     int next;           // next free internal id
     int depth;          // huffman.h:26 high-water mark
@@ -328,6 +328,7 @@ struct Tree {
     int lut_ok;         // decoder: the lookup table matches the tree
 
     static constexpr int kRoot = LEAVES;
+    static constexpr int kLutBits = LUT_BITS;      // decoder table: 2^kLutBits entries
     static constexpr int kIdEnd =
         (LEAVES + 1 + REF_LEAVES - 2) < NODES ? (LEAVES + 1 + REF_LEAVES - 2) : NODES;
 
@@ -622,17 +623,16 @@ __device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, Tr
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs());
 }
 
-// decoder: table over the next 8 stream bits -> (node reached, bits used).
+// decoder: table over the next kLutBits stream bits -> (node reached, bits used).
 // Entry = node | used << 10; a missing child gives node = kNil.
 template <class T>
 __device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut, int lane) {
 #pragma unroll 1
-    for (int j = 0; j < 4; j++) {
-        const int idx = lane + 64 * j;
+    for (int idx = lane; idx < (1 << T::kLutBits); idx += kWave) {
         int node = T::kRoot, used = 0;
-        for (int level = 0; level < 8; level++) {
+        for (int level = 0; level < T::kLutBits; level++) {
             const uint32_t kids = (uint32_t)(link[node] >> 32);
-            const int bit = (idx >> (7 - level)) & 1;
+            const int bit = (idx >> (T::kLutBits - 1 - level)) & 1;
             const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
             used = level + 1;
             node = child;
@@ -647,13 +647,13 @@ constexpr int kLitNodes  = kLitLeaves + 288;  // root + <=285 splits (+pad)
 constexpr int kPosLeaves = 32;
 constexpr int kPosNodes  = 64;
 
-using LitTree = Tree<kLitLeaves, kLitNodes, 512>;
-using PosTree = Tree<kPosLeaves, kPosNodes, 32>;
+using LitTree = Tree<kLitLeaves, kLitNodes, 512, 8>;
+using PosTree = Tree<kPosLeaves, kPosNodes, 32, 6>;
 
 // LDS image of one stream's entropy state
 struct DecodeLuts {
-    uint16_t lit[256];
-    uint16_t pos[256];
+    uint16_t lit[1 << 8];
+    uint16_t pos[1 << 6];
 };
 
 struct EntropyLds {
