@@ -30,7 +30,7 @@ struct DecodeLds {
     EntropyLds entropy;
     DecodeLuts luts;
     uint32_t   stage[kStageDw];
-    uint2      slot[kWave];             // read-ahead tokens: word, bits used
+    uint32_t   slot[2 * kWave];         // read-ahead tokens: word | (bits used - 1) << 25
 };
 
 // squeeze.h:429-442; returns the leaf or -1 with err set.  The first 8 levels
@@ -189,8 +189,6 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         uint64_t base = bit0;
         int m = 0;
         bool stop = frozen;
-        int myslot = -1;
-        uint32_t my_word = 0, my_used = 0;
         while (m < kWave && !stop) {
             const uint32_t k0 = (uint32_t)(base >> 5);
             if (k0 < sdw || ((uint32_t)((base + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
@@ -256,31 +254,39 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 }
             }
             const bool ok = !bad && !esc && used <= 64u && o + used <= r.readable;
-            const uint64_t okmask = __ballot(ok);
-            // follow the token lengths from offset 0 of this round
+            // follow the token lengths from offset 0 of this round: a token that cannot be
+            // taken here jumps out of the round (>= 128) and ends the read-ahead
+            const int hop = ok ? (int)used : 128;
+            uint64_t starts = 0;
             uint32_t s = 0;
-            while (s < (uint32_t)kWave && m < kWave) {
-                if (((okmask >> s) & 1ull) == 0) { stop = true; break; }
-                if ((uint32_t)lane == s) { myslot = m; my_word = word; my_used = used; }
-                s += (uint32_t)__builtin_amdgcn_readlane((int)used, (int)s);
-                m++;
+            do {
+                starts |= 1ull << s;
+                s += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s);
+            } while (s < (uint32_t)kWave);
+            if (s >= 128u) {                                      // the last start is the refused one
+                stop = true;
+                const int last = 63 - __builtin_clzll(starts);
+                starts &= ~(1ull << last);
+                s = (uint32_t)last;
             }
             base += s;
-            // hand this round's picks to the slots (a lane may be picked again next round)
-            if (myslot >= 0) { lds.slot[myslot] = make_uint2(my_word, my_used); myslot = -1; }
+            // hand this round's picks to the slots, in order (slots past 64 are never used)
+            if ((starts >> lane) & 1ull) {
+                const int at = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+                lds.slot[at] = word | ((used - 1u) << 25);
+            }
+            m += __builtin_popcountll(starts);
         }
+        m = m < kWave ? m : kWave;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // ---- lane j = token j: positions, validity, symbols ---------------------------------
         uint32_t word_v = 0, used_v = 0;
-        if (lane < m) { const uint2 sl = lds.slot[lane]; word_v = sl.x; used_v = sl.y; }
+        if (lane < m) { const uint32_t sl = lds.slot[lane]; word_v = sl & 0x81FFFFFFu; used_v = ((sl >> 25) & 63u) + 1u; }
         const bool is_match = (word_v & kTokMatch) != 0;
         const uint32_t tlen_v = lane < m ? (is_match ? ((word_v >> 16) & 0x1FFu) : 1u) : 0u;
         uint32_t scan = (used_v << 16) | tlen_v;               // both sums fit 16 bits
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t up = __shfl_up(scan, d);
-            if (lane >= d) { scan += up; }
-        }
+        scan = wave_scan(scan);
         const uint64_t out_before = i + (uint64_t)((scan & 0xFFFFu) - tlen_v);
         const bool invalid = lane < m &&
             (out_before >= bytes ||
@@ -375,11 +381,7 @@ void lz_expand_kernel(const uint32_t* __restrict__ tokens,
             mylen = (word & kTokMatch) ? ((word >> 16) & 0x1FFu) : 1u;
         }
         uint32_t incl = mylen;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) { incl += up; }
-        }
+        incl = wave_scan(incl);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
         uint64_t room = (uint64_t)kExpRegion - (i - base);
         if ((uint64_t)total > room && (i - base) > 32767 + kExpSlack) {

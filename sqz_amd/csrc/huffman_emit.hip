@@ -83,11 +83,7 @@ struct BitQueue {
     // full words leave for HBM
     __device__ __forceinline__ void pack_lanes(uint64_t v, uint32_t n, int lane) {
         uint32_t incl = n;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) { incl += up; }
-        }
+        incl = wave_scan(incl);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + (uint32_t)carry;
         if (n != 0) {
             const uint32_t o = (uint32_t)carry + incl - n;  // first stream bit of this lane's bits

@@ -147,11 +147,7 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
 #pragma unroll
             for (int j = 0; j < 4; j++) { v[j] = lds.total[4 * lane + j]; s += v[j]; }
             uint32_t incl = s;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) { incl += up; }
-            }
+            incl = wave_scan(incl);
             uint32_t excl = incl - s;
 #pragma unroll
             for (int j = 0; j < 4; j++) { lds.total[4 * lane + j] = excl; excl += v[j]; }
