@@ -177,6 +177,13 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     };
 
     uint32_t sdw = 0xFFFFFFFFu;                      // stream dword held by stage[0] (none yet)
+#ifdef SQZ_STATS
+    uint32_t st_steps = 0, st_rounds = 0, st_m = 0, st_done = 0, st_hist[5] = {0, 0, 0, 0, 0};
+    uint64_t st_sec[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_begin = st_last;
+#define ST_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); st_sec[k] += n_ - st_last; st_last = n_; }
+#else
+#define ST_SEC(k)
+#endif
     while (i < bytes && err == 0) {
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
                             ntok > (1u << 24);
@@ -254,8 +261,12 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 }
             }
             const bool ok = !bad && !esc && used <= 64u && o + used <= r.readable;
+#ifdef SQZ_STATS
+            st_rounds++;
+#endif
             // follow the token lengths from offset 0 of this round: a token that cannot be
             // taken here jumps out of the round (>= 128) and ends the read-ahead
+            ST_SEC(0)
             const int hop = ok ? (int)used : 128;
             uint64_t starts = 0;
             uint32_t s = 0;
@@ -277,8 +288,10 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 lds.slot[at] = word | ((used - 1u) << 25);
             }
             m += __builtin_popcountll(starts);
+            ST_SEC(1)
         }
         m = m < kWave ? m : kWave;
+        ST_SEC(1)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // ---- lane j = token j: positions, validity, symbols ---------------------------------
         uint32_t word_v = 0, used_v = 0;
@@ -306,7 +319,9 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         uint64_t ca, cb;
         int wa, wb;
         int done = 0;
+        ST_SEC(2)
         if (m > 0) { done = bump_lanes(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        ST_SEC(3)
         uint64_t resume = bit0;
         if (done > 0) {
             if (lane < done) { tok[ntok + (uint32_t)lane] = word_v; }
@@ -317,8 +332,25 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         }
         r.seek(resume);
         // ---- whatever stopped the step: one token, exactly ------------------------------------
+#ifdef SQZ_STATS
+        st_steps++; st_m += (uint32_t)m; st_done += (uint32_t)done;
+        st_hist[done == 0 ? 0 : done < 8 ? 1 : done < 24 ? 2 : done < 64 ? 3 : 4]++;
+#endif
+        ST_SEC(4)
         if (i < bytes && done < kWave) { decode_one(); }
+        ST_SEC(5)
     }
+#ifdef SQZ_STATS
+    if (lane == 0 && b == 1) {
+        printf("block %u: tokens %u steps %u rounds %u sum_m %u sum_done %u hist[0,<8,<24,<64,64] %u %u %u %u %u\n", b, ntok,
+               st_steps, st_rounds, st_m, st_done, st_hist[0], st_hist[1], st_hist[2], st_hist[3], st_hist[4]);
+        printf("cycles total %llu: round %llu hop+slot %llu post %llu bump %llu store %llu exact %llu\n", (unsigned long long)(st_last - st_begin),
+               (unsigned long long)st_sec[0], (unsigned long long)st_sec[1], (unsigned long long)st_sec[2], (unsigned long long)st_sec[3], (unsigned long long)st_sec[4], (unsigned long long)st_sec[5]);
+        printf("lit slow: insert %u/%llu changed %u/%llu lut %u/%llu; pos: insert %u/%llu changed %u/%llu lut %u/%llu\n",
+               lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1], lit.st_cnt[2], (unsigned long long)lit.st_cyc[2],
+               pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1], pos.st_cnt[2], (unsigned long long)pos.st_cyc[2]);
+    }
+#endif
     if (lane == 0) {
         tok_count[b] = ntok;
         err_out[b] = err;

@@ -530,23 +530,38 @@ struct Tree {
     }
 
     // whole wave: insert through lane 0 (unseen symbols are rare: <= 286 per stream)
+#ifdef SQZ_STATS
+    uint64_t st_cyc[3] = {0, 0, 0};
+    uint32_t st_cnt[3] = {0, 0, 0};
+#define SQZ_ST_BEGIN const uint64_t st_t0 = __builtin_readcyclecounter();
+#define SQZ_ST_END(k) st_cyc[k] += __builtin_readcyclecounter() - st_t0; st_cnt[k]++;
+#else
+#define SQZ_ST_BEGIN
+#define SQZ_ST_END(k)
+#endif
     __device__ __forceinline__ bool insert_wave(int i, int lane) {
+        SQZ_ST_BEGIN
         const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)slow_insert<Tree>(link, freq, scratch, pack_regs(), i, lane));
         unpack_regs(r);
         lut_ok = 0;
+        SQZ_ST_END(0)
         return (r >> 31) != 0;
     }
 
     __device__ __forceinline__ void changed_wave(int s, int lane) {
+        SQZ_ST_BEGIN
         unpack_regs((uint32_t)__builtin_amdgcn_readfirstlane(
             (int)slow_changed<Tree>(link, freq, scratch, pack_regs(), s, lane)));
         lut_ok = 0;
+        SQZ_ST_END(1)
     }
 
     __device__ __forceinline__ void build_lut(int lane) {
+        SQZ_ST_BEGIN
         slow_build_lut<Tree>(link, lut, lane);
         lut_ok = 1;
+        SQZ_ST_END(2)
     }
 
     // ---------------- fast path ------------------------------------------------
@@ -579,6 +594,149 @@ struct Tree {
         c.active = lane < levels;
         c.has_g = lane + 1 < levels;
         return c;
+    }
+
+    // ---------------- restructuring, whole wave --------------------------------
+    // The same sequence as changed() above (huffman.h:130-147, :98-128), with the
+    // per-level work of a climb done by one lane per level and the pending
+    // (parent, child) pairs tested all at once.  Uniform control flow.
+
+    // sibling order under i's parent (huffman.h:64-86) without the relabel: a swap
+    // changes codes, never depths, and codes are read off the chain when needed
+    __device__ __forceinline__ void order_only(int i) {
+        const uint32_t p = up_of(i);
+        if (p == kNil) { return; }
+        Node n = ld((int)p);
+        if (n.lo != kNil && n.hi != kNil && freq[n.lo] > freq[n.hi]) {
+            const uint32_t l = n.lo;
+            n.lo = n.hi; n.hi = l;
+            st((int)p, n);
+        }
+    }
+
+    // depth / up2 / up3 of every attached node from its parent's, repeated until
+    // nothing moves (one pass per level of the subtree that changed).  `reset`:
+    // the reference walked from the root, which restarts the depth high-water mark.
+    __device__ __forceinline__ void relabel_wave(bool reset, int lane) {
+        if (reset) { depth = 0; }
+        uint32_t seen = 0;
+        for (int pass = 0; pass < 70; pass++) {
+            bool moved = false;
+            uint32_t all = 0;
+            for (int v = lane; v < next; v += kWave) {
+                const uint64_t w = link[v];
+                const uint32_t up = (uint32_t)w & 0x3FFu;
+                if (up == kNil) { continue; }                       // the root, or not in the tree
+                const uint64_t pw = link[up];
+                uint32_t d = (((uint32_t)(pw >> 32) >> 20) & 0x3Fu) + 1u;
+                if (d > 63u || (d == 63u && v >= LEAVES)) { fault = 1; d = d > 63u ? 63u : d; }
+                const uint32_t lo_w = up | (((uint32_t)pw & 0xFFFFFu) << 10);
+                const uint32_t hi_w = ((uint32_t)(w >> 32) & 0xFFFFFu) | (d << 20);
+                all = d > all ? d : all;
+                if (lo_w != (uint32_t)w || hi_w != (uint32_t)(w >> 32)) {
+                    link[v] = (uint64_t)lo_w | ((uint64_t)hi_w << 32);
+                    seen = d > seen ? d : seen;
+                    moved = true;
+                }
+            }
+            if (__ballot(moved) == 0) { if (reset) { seen = all; } break; }
+        }
+        // wave maximum of `seen` -> the high-water mark
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)seen, o);
+            seen = other > seen ? other : seen;
+        }
+        const int top = __builtin_amdgcn_readfirstlane((int)seen);
+        if (top > depth) { depth = top; }
+        fault = (__ballot(fault != 0) != 0) ? 1 : 0;
+    }
+
+    // the climb of huffman_frequency_changed from node i (huffman.h:132-142): lane k
+    // owns level k of i's root path; new sums by prefix sum, sibling order per level,
+    // one pending pair per level (bottom first)
+    __device__ __forceinline__ int climb_wave(int i, int sp, int lane) {
+        const Chain c = chain_up(i, lane);
+        const int levels = c.levels;
+        if (levels >= kMaxFastDepth || sp + levels > kWave) { fault = 1; return 0; }
+        if (levels == 0) {                                            // i is the root
+            if (lane == 0) { sum(i); }
+            return sp;
+        }
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)freq[i]);
+        const int x = c.active ? c.mine : kRoot;
+        const int p = c.active ? c.par : kRoot;
+        const Node lp = ld(p);
+        const bool is_hi = lp.hi == (uint32_t)x;
+        const uint32_t sib = is_hi ? lp.lo : lp.hi;
+        const bool has_sib = c.active & (sib != kNil);
+        const uint32_t fs = has_sib ? freq[sib] : 0u;
+        const uint32_t incl = wave_scan(c.active ? fs : 0u);
+        const uint32_t fx = f0 + incl - fs;                          // my node's count, refreshed
+        const bool swap = has_sib & (is_hi ? (fs > fx) : (fx > fs));  // lo count > hi count
+        if (c.active) {
+            freq[p] = f0 + incl;
+            if (swap) {
+                Node n = lp;
+                n.lo = lp.hi; n.hi = lp.lo;
+                st(p, n);
+            }
+            scratch->pend[sp + lane] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
+        }
+        if ((__ballot(swap) >> (levels - 1)) & 1ull) { relabel_wave(true, lane); }   // swapped under the root
+        return sp + levels;
+    }
+
+    __device__ __forceinline__ void changed_all(int start, int lane) {
+        int sp = climb_wave(start, 0, lane);
+        while (sp > 0) {
+            // every pending pair at once: the reference pops them from the top and the
+            // ones that fail its tests (:143, :108) change nothing
+            bool hit = false;
+            int p = 0, ch = 0, g = 0, uncle = 0, left = 0;
+            if (lane < sp) {
+                const uint32_t e = scratch->pend[lane];
+                p = (int)(e >> 16); ch = (int)(e & 0xFFFFu);
+                const Node np = ld(p);
+                if (np.up != kNil && np.hi == (uint32_t)ch) {
+                    g = (int)np.up;
+                    const Node ng = ld(g);
+                    left = ng.lo == (uint32_t)p ? 1 : 0;
+                    uncle = (int)(left ? ng.hi : ng.lo);
+                    hit = uncle != (int)kNil && freq[ch] > freq[uncle];
+                }
+            }
+            const uint64_t hits = __ballot(hit);
+            if (hits == 0) { break; }
+            const int j = 63 - __builtin_clzll(hits);
+            sp = j;
+            p = __builtin_amdgcn_readlane(p, j);
+            ch = __builtin_amdgcn_readlane(ch, j);
+            g = __builtin_amdgcn_readlane(g, j);
+            uncle = __builtin_amdgcn_readlane(uncle, j);
+            left = __builtin_amdgcn_readlane(left, j);
+            if (lane == 0) {                                          // move_up, :110-125
+                Node nc = ld(ch);
+                nc.up = (uint32_t)g;
+                st(ch, nc);
+                Node ng = ld(g);
+                if (left) { ng.hi = (uint32_t)ch; } else { ng.lo = (uint32_t)ch; }
+                st(g, ng);
+                Node npar = ld(p);
+                npar.hi = (uint32_t)uncle;
+                st(p, npar);
+                Node nu = ld(uncle);
+                nu.up = (uint32_t)p;
+                st(uncle, nu);
+                sum(p);
+                sum(g);
+                order_only(ch);
+                order_only(uncle);
+                order_only(p);
+            }
+            relabel_wave(g == kRoot, lane);
+            sp = climb_wave(g, sp, lane);                             // :126
+        }
     }
 
     // huffman_inc_frequency for an ATTACHED leaf s whose chain is `c`.
@@ -630,7 +788,12 @@ __device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, Tr
     T t;
     t.link = link; t.freq = freq; t.scratch = scratch; t.lut = nullptr; t.lut_ok = 0;
     t.unpack_regs(regs);
-    if (lane == 0) { t.freq[sym] += 1; t.changed(sym); }
+    if (t.depth + 4 >= kMaxFastDepth) {                 // chains too long for one lane per level
+        if (lane == 0) { t.freq[sym] += 1; t.changed(sym); }
+    } else {
+        if (lane == 0) { t.freq[sym] += 1; }
+        t.changed_all(sym, lane);
+    }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs());
 }
 
