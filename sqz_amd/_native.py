@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsqz_amd.so")
+# SQZ_AMD_LIB: developer override (an instrumented build of the same sources)
+LIB_PATH = os.environ.get("SQZ_AMD_LIB") or os.path.join(_HERE, "lib", "libsqz_amd.so")
 
 
 class Bitstream(C.Structure):

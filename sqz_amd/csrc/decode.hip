@@ -177,9 +177,11 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     };
 
     uint32_t sdw = 0xFFFFFFFFu;                      // stream dword held by stage[0] (none yet)
+    int want = 8, avg4 = 16;                         // read-ahead depth follows the recent step lengths (avg4 = 4 x mean)
 #ifdef SQZ_STATS
     uint32_t st_steps = 0, st_rounds = 0, st_m = 0, st_done = 0, st_hist[5] = {0, 0, 0, 0, 0};
     uint64_t st_sec[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_begin = st_last;
+    const uint64_t st_wall0 = wall_clock64();
 #define ST_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); st_sec[k] += n_ - st_last; st_last = n_; }
 #else
 #define ST_SEC(k)
@@ -196,7 +198,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         uint64_t base = bit0;
         int m = 0;
         bool stop = frozen;
-        while (m < kWave && !stop) {
+        while (m < want && !stop) {
             const uint32_t k0 = (uint32_t)(base >> 5);
             if (k0 < sdw || ((uint32_t)((base + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
                 sdw = k0;
@@ -305,7 +307,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             (out_before >= bytes ||
              (is_match && ((uint64_t)(word_v & 0x7FFFu) > out_before || (uint64_t)tlen_v > bytes - out_before)));
         const uint64_t inv = __ballot(invalid);
-        if (inv != 0) { const int f = __builtin_ctzll(inv); m = f < m ? f : m; }
+        if (inv != 0) { const int f = __builtin_ctzll(inv); if (f < m) { m = f; stop = true; } }
         int a_v = -1, b_v = -1;
         if (lane < m) {
             if (is_match) {
@@ -337,15 +339,24 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         st_hist[done == 0 ? 0 : done < 8 ? 1 : done < 24 ? 2 : done < 64 ? 3 : 4]++;
 #endif
         ST_SEC(4)
-        if (i < bytes && done < kWave) { decode_one(); }
-        ST_SEC(5)
+        if (i < bytes && (stop || done < m)) { decode_one(); }
+        {   // a step that ran short is usually followed by more short ones (the tree is still moving)
+            avg4 += done - (avg4 >> 2);
+            want = (avg4 >> 1) + 6;                           // twice the recent mean, and a little
+            want = want < kWave ? want : kWave;
+        }
     }
 #ifdef SQZ_STATS
+    if (lane == 0 && (b % 512 == 7 || b == n_blocks - 1)) {
+        printf("wall block %u: start %llu end %llu (100 MHz ticks), cycles %llu\n", b, (unsigned long long)st_wall0,
+               (unsigned long long)wall_clock64(), (unsigned long long)(__builtin_readcyclecounter() - st_begin));
+    }
     if (lane == 0 && b == 1) {
         printf("block %u: tokens %u steps %u rounds %u sum_m %u sum_done %u hist[0,<8,<24,<64,64] %u %u %u %u %u\n", b, ntok,
                st_steps, st_rounds, st_m, st_done, st_hist[0], st_hist[1], st_hist[2], st_hist[3], st_hist[4]);
         printf("cycles total %llu: round %llu hop+slot %llu post %llu bump %llu store %llu exact %llu\n", (unsigned long long)(st_last - st_begin),
                (unsigned long long)st_sec[0], (unsigned long long)st_sec[1], (unsigned long long)st_sec[2], (unsigned long long)st_sec[3], (unsigned long long)st_sec[4], (unsigned long long)st_sec[5]);
+        printf("bump: open %llu count %llu mid %llu add %llu count-iters %llu\n", g_st[0], g_st[1], g_st[2], g_st[3], g_st[4]);
         printf("lit slow: insert %u/%llu changed %u/%llu lut %u/%llu; pos: insert %u/%llu changed %u/%llu lut %u/%llu\n",
                lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1], lit.st_cnt[2], (unsigned long long)lit.st_cyc[2],
                pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1], pos.st_cnt[2], (unsigned long long)pos.st_cyc[2]);

@@ -801,18 +801,29 @@ __device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, Tr
 // Entry = node | used << 10; a missing child gives node = kNil.
 template <class T>
 __device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut, int lane) {
+    // every lane follows its table entries down the tree together, one level per
+    // round trip (the walks are independent, so their reads overlap)
+    constexpr int kPer = (1 << T::kLutBits) / kWave > 0 ? (1 << T::kLutBits) / kWave : 1;
+    int node[kPer], used[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; e++) { node[e] = T::kRoot; used[e] = 0; }
 #pragma unroll 1
-    for (int idx = lane; idx < (1 << T::kLutBits); idx += kWave) {
-        int node = T::kRoot, used = 0;
-        for (int level = 0; level < T::kLutBits; level++) {
-            const uint32_t kids = (uint32_t)(link[node] >> 32);
+    for (int level = 0; level < T::kLutBits; level++) {
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int idx = e * kWave + lane;
+            const bool inside = node[e] != (int)kNil && node[e] >= (int)T::kRoot;
+            const uint32_t kids = (uint32_t)(link[inside ? node[e] : (int)T::kRoot] >> 32);
             const int bit = (idx >> (T::kLutBits - 1 - level)) & 1;
             const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
-            used = level + 1;
-            node = child;
-            if (child == (int)kNil || child < (int)T::kRoot) { break; }
+            node[e] = inside ? child : node[e];
+            used[e] += inside ? 1 : 0;
         }
-        lut[idx] = (uint16_t)(node | (used << 10));
+    }
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const int idx = e * kWave + lane;
+        if (idx < (1 << T::kLutBits)) { lut[idx] = (uint16_t)(node[e] | (used[e] << 10)); }
     }
 }
 
@@ -943,51 +954,80 @@ constexpr uint32_t kCntShift = 25;
 constexpr uint32_t kCntOne = 1u << kCntShift;
 constexpr uint32_t kCountMask = kCntOne - 1u;
 
-__device__ __forceinline__ void lanes_add(const uint64_t* link, uint32_t* freq, int leaf, uint32_t delta) {
-    if (leaf < 0) { return; }
-    const int base = leaf >= kLitNodes ? kLitNodes : 0;
-    uint32_t c = (uint32_t)(leaf - base);
-    while (c != kNil) {
-        atomicAdd(&freq[base + (int)c], delta);
-        c = reinterpret_cast<const uint32_t*>(link)[2 * (base + (int)c)] & 0x3FFu;
-    }
-}
+// One lane's walk up one chain, three levels per round trip: a node's word names
+// its parent, grandparent and great-grandparent, so their counters and child links
+// are fetched together.  Written without branches so that the walks of a lane's
+// two symbols interleave; a finished walk keeps issuing harmless accesses (adds
+// of 0, reads of its last node) until the other one is done.
+#ifdef SQZ_STATS
+__device__ unsigned long long g_st[8];
+#endif
+struct LaneWalk {
+    int base;
+    uint32_t c;          // node whose counter comes next
+    uint64_t w;          // its word
+    bool live, bad, prev_hi;
+    uint32_t prev_reach;
+    int k;
+    uint32_t code;       // hi/lo choices, leaf level first (walks deeper than 30 go to the serial path)
 
-// sweep 1 for one symbol of this lane; returns true when the lane is bad
-__device__ __forceinline__ bool lanes_count(const uint64_t* link, uint32_t* freq, int leaf,
-                                            uint64_t& code, int& depth) {
-    code = 0; depth = 0;
-    if (leaf < 0) { return false; }
-    const int base = leaf >= kLitNodes ? kLitNodes : 0;
-    uint32_t c = (uint32_t)(leaf - base);
-    uint32_t p = (uint32_t)link[base + (int)c] & 0x3FFu;
-    bool bad = false, prev_hi = false;
-    uint32_t prev_reach = 0;
-    int k = 0;
-    for (;;) {
-        const uint32_t old = atomicAdd(&freq[base + (int)c], kCntOne);
-        if (p == kNil) { break; }                                        // the root: counted, no test
-        const uint32_t f0c = old & kCountMask;
-        const uint32_t reach = f0c + (old >> kCntShift) + 1u;            // my count of c after my add
-        const uint64_t wp = link[base + (int)p];
-        const uint32_t kids = (uint32_t)(wp >> 32);
+    __device__ __forceinline__ void open(const uint64_t* link, int leaf) {
+        live = leaf >= 0; bad = false; prev_hi = false; prev_reach = 0; k = 0; code = 0;
+        base = leaf >= kLitNodes ? kLitNodes : 0;
+        c = live ? (uint32_t)(leaf - base) : 0u;
+        w = link[base + (int)c];
+    }
+
+    // the tests at one level: `node` (counter value before my add: `old`) under a parent
+    // whose children are `kids`
+    __device__ __forceinline__ void level(const uint32_t* freq, uint32_t node, uint32_t old, uint32_t kids,
+                                          bool valid) {
         const uint32_t lo = kids & 0x3FFu, hi = (kids >> 10) & 0x3FFu;
-        const bool is_hi = (hi == c);
+        const bool is_hi = (hi == node);
         const uint32_t sib = is_hi ? lo : hi;
-        const bool has_sib = sib != kNil;
-        const uint32_t f0s = freq[base + (int)(has_sib ? sib : p)] & kCountMask;
+        const bool has_sib = valid & (sib != kNil);
+        const uint32_t f0s = freq[base + (int)(has_sib ? sib : node)] & kCountMask;
+        const uint32_t f0c = old & kCountMask;
+        const uint32_t reach = f0c + (old >> kCntShift) + 1u;            // my count of the node after my add
         bad |= has_sib & (is_hi ? (f0s > f0c + 1u) : (reach > f0s));     // swap tests
         bad |= prev_hi & has_sib & (prev_reach > f0s);                   // promote test of the level below
-        code |= (uint64_t)(is_hi ? 1u : 0u) << k;
-        k++;
-        prev_hi = is_hi; prev_reach = reach;
-        c = p;
-        p = (uint32_t)wp & 0x3FFu;
-        if (k >= 48) { bad = true; }                                     // never: left to the serial path
+        code |= ((valid & is_hi) ? 1u : 0u) << k;
+        k += valid ? 1 : 0;
+        prev_hi = valid ? is_hi : prev_hi;
+        prev_reach = valid ? reach : prev_reach;
     }
-    depth = k;
-    return bad;
-}
+
+    // sweep 1: count + test + code, three levels
+    __device__ __forceinline__ void count3(const uint64_t* link, uint32_t* freq) {
+        const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
+        const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
+        const uint32_t i1 = v1 ? p1 : c, i2 = v2 ? p2 : c, i3 = v3 ? p3 : c;
+        const uint32_t kids1 = (uint32_t)(link[base + (int)i1] >> 32);
+        const uint32_t kids2 = (uint32_t)(link[base + (int)i2] >> 32);
+        const uint64_t w3 = link[base + (int)i3];
+        uint32_t old0 = 0, old1 = 0, old2 = 0;
+        if (live) { old0 = atomicAdd(&freq[base + (int)c], kCntOne); }
+        if (v1) { old1 = atomicAdd(&freq[base + (int)i1], kCntOne); }
+        if (v2) { old2 = atomicAdd(&freq[base + (int)i2], kCntOne); }
+        level(freq, c, old0, kids1, v1);
+        level(freq, p1, old1, kids2, v2);
+        level(freq, p2, old2, (uint32_t)(w3 >> 32), v3);
+        if (k >= 29) { bad = true; }                                     // never: left to the serial path
+        live = v3; c = i3; w = w3;
+    }
+
+    // sweep 2: three levels
+    __device__ __forceinline__ void add3(const uint64_t* link, uint32_t* freq, uint32_t delta) {
+        const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
+        const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
+        const uint32_t i1 = v1 ? p1 : c, i2 = v2 ? p2 : c, i3 = v3 ? p3 : c;
+        const uint64_t w3 = link[base + (int)i3];
+        if (live) { atomicAdd(&freq[base + (int)c], delta); }
+        if (v1) { atomicAdd(&freq[base + (int)i1], delta); }
+        if (v2) { atomicAdd(&freq[base + (int)i2], delta); }
+        live = v3; c = i3; w = w3;
+    }
+};
 
 // Whole wave: lanes [0, m) offer their symbols (a, then b; unified leaf ids, -1 = none).
 // Returns how many leading tokens were applied (0..m); codes/depths are valid for those.
@@ -995,13 +1035,37 @@ __device__ __forceinline__ int bump_lanes(uint64_t* link, uint32_t* freq, int la
                                           uint64_t& code_a, int& depth_a, uint64_t& code_b, int& depth_b) {
     const bool take = lane < m;
     const int la = take ? a : -1, lb = take ? b : -1;
-    bool bad = lanes_count(link, freq, la, code_a, depth_a);
-    bad |= lanes_count(link, freq, lb, code_b, depth_b);
-    const uint64_t bm = __ballot(bad);
+    LaneWalk wa, wb;
+#ifdef SQZ_STATS
+    uint64_t t0_ = __builtin_readcyclecounter();
+#define BL_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); if (blockIdx.x == 1 && threadIdx.x == 0) { g_st[k] += n_ - t0_; } t0_ = n_; }
+#else
+#define BL_SEC(k)
+#endif
+    wa.open(link, la);
+    wb.open(link, lb);
+    BL_SEC(0)
+    while (__ballot(wa.live | wb.live) != 0) {
+        wa.count3(link, freq);
+        if (__ballot(wb.live) != 0) { wb.count3(link, freq); }
+#ifdef SQZ_STATS
+        if (blockIdx.x == 1 && threadIdx.x == 0) { g_st[4] += 1; }
+#endif
+    }
+    BL_SEC(1)
+    code_a = wa.code; depth_a = wa.k;
+    code_b = wb.code; depth_b = wb.k;
+    const uint64_t bm = __ballot(wa.bad | wb.bad);
     const int ok = bm != 0 ? __builtin_ctzll(bm) : m;                    // tokens in front of the first bad lane
     const uint32_t delta = lane < ok ? (1u - kCntOne) : (0u - kCntOne);
-    lanes_add(link, freq, la, delta);
-    lanes_add(link, freq, lb, delta);
+    wa.open(link, la);
+    wb.open(link, lb);
+    BL_SEC(2)
+    while (__ballot(wa.live | wb.live) != 0) {
+        wa.add3(link, freq, delta);
+        if (__ballot(wb.live) != 0) { wb.add3(link, freq, delta); }
+    }
+    BL_SEC(3)
     return ok < m ? ok : m;
 }
 
