@@ -180,7 +180,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     int want = 8, avg4 = 16;                         // read-ahead depth follows the recent step lengths (avg4 = 4 x mean)
 #ifdef SQZ_STATS
     uint32_t st_steps = 0, st_rounds = 0, st_m = 0, st_done = 0, st_hist[5] = {0, 0, 0, 0, 0};
-    uint64_t st_sec[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_begin = st_last;
+    uint64_t st_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_begin = st_last;
     const uint64_t st_wall0 = wall_clock64();
 #define ST_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); st_sec[k] += n_ - st_last; st_last = n_; }
 #else
@@ -217,6 +217,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             const int sh = (int)(o & 31u);
             const uint32_t d0 = lds.stage[k], d1 = lds.stage[k + 1], d2 = lds.stage[k + 2];
             uint64_t w = ((((uint64_t)d0 << 32) | d1) << sh) | (sh ? ((uint64_t)d2 >> (32 - sh)) : 0ull);
+            ST_SEC(6)
             // literal / length symbol
             uint32_t e = lds.luts.lit[(uint32_t)(w >> 56)];
             uint32_t node = e & 0x3FFu;
@@ -232,35 +233,43 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                     used++;
                 }
             }
+            ST_SEC(7)
             bool bad = node >= (uint32_t)kLitLeaves;              // nil / still inside
             bool esc = node == (uint32_t)kLitNyt;
+            // squeeze.h:458-500, read only.  Every lane goes through the back-reference
+            // fields (some lane nearly always holds a length code, so branches would only
+            // cost mask bookkeeping); a literal's lane uses harmless indices and keeps
+            // its own word.
+            const bool is_len = !bad && !esc && node > 0xFFu;
+            int bs, xb;
+            len_base_of(is_len ? (int)node - kSymLen0 : 0, bs, xb);
+            const uint32_t len = (uint32_t)bs + (__brev((uint32_t)(w >> 32)) & ((1u << xb) - 1u));
+            w <<= xb;
+            uint32_t more_bits = (uint32_t)xb;
+            const uint32_t e2 = lds.luts.pos[(uint32_t)(w >> (64 - PosTree::kLutBits))];
+            uint32_t n2 = e2 & 0x3FFu;
+            w <<= (e2 >> 10);
+            more_bits += e2 >> 10;
+            for (int it = 0; it < 56; it++) {                      // deeper than the table
+                const bool more = is_len && n2 >= (uint32_t)kPosLeaves && n2 != kNil;
+                if (__ballot(more) == 0) { break; }
+                const uint32_t kids = (uint32_t)(link[kLitNodes + (more ? (int)n2 : (int)kPosLeaves)] >> 32);
+                const uint32_t down = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
+                n2 = more ? down : n2;
+                w <<= more ? 1 : 0;
+                more_bits += more ? 1u : 0u;
+            }
+            const bool pos_bad = n2 >= (uint32_t)kPosLeaves;      // nil / still inside
+            const bool pos_esc = n2 == (uint32_t)kPosNyt;
+            pos_base_of(pos_bad ? 0 : (int)n2, bs, xb);
+            const uint32_t dist = (uint32_t)bs + (__brev((uint32_t)(w >> 32)) & ((1u << xb) - 1u));
+            more_bits += (uint32_t)xb;
             uint32_t word = node;
-            if (!bad && !esc && node > 0xFFu) {                    // squeeze.h:458-500, read only
-                int bs, xb;
-                len_base_of((int)node - kSymLen0, bs, xb);
-                uint32_t len = (uint32_t)bs;
-                if (xb) { len += __brev((uint32_t)(w >> (64 - xb))) >> (32 - xb); }
-                w <<= xb; used += (uint32_t)xb;
-                const uint32_t e2 = lds.luts.pos[(uint32_t)(w >> (64 - PosTree::kLutBits))];
-                uint32_t n2 = e2 & 0x3FFu;
-                w <<= (e2 >> 10); used += (e2 >> 10);
-                for (int it = 0; it < 56; it++) {
-                    if (!(n2 >= (uint32_t)kPosLeaves && n2 != kNil)) { break; }
-                    const uint32_t kids = (uint32_t)(link[kLitNodes + (int)n2] >> 32);
-                    n2 = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
-                    w <<= 1;
-                    used++;
-                }
-                bad |= n2 >= (uint32_t)kPosLeaves;
-                esc |= n2 == (uint32_t)kPosNyt;
-                if (!bad && !esc) {
-                    pos_base_of((int)n2, bs, xb);
-                    uint32_t dist = (uint32_t)bs;
-                    if (xb) { dist += __brev((uint32_t)(w >> (64 - xb))) >> (32 - xb); }
-                    used += (uint32_t)xb;
-                    bad |= len > (uint32_t)kLenMax;
-                    word = kTokMatch | (len << 16) | dist;
-                }
+            if (is_len) {
+                bad = pos_bad | (len > (uint32_t)kLenMax);
+                esc = pos_esc;
+                used += more_bits;
+                word = kTokMatch | (len << 16) | dist;
             }
             const bool ok = !bad && !esc && used <= 64u && o + used <= r.readable;
 #ifdef SQZ_STATS
@@ -340,6 +349,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
 #endif
         ST_SEC(4)
         if (i < bytes && (stop || done < m)) { decode_one(); }
+        ST_SEC(5)
         {   // a step that ran short is usually followed by more short ones (the tree is still moving)
             avg4 += done - (avg4 >> 2);
             want = (avg4 >> 1) + 6;                           // twice the recent mean, and a little
@@ -356,6 +366,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                st_steps, st_rounds, st_m, st_done, st_hist[0], st_hist[1], st_hist[2], st_hist[3], st_hist[4]);
         printf("cycles total %llu: round %llu hop+slot %llu post %llu bump %llu store %llu exact %llu\n", (unsigned long long)(st_last - st_begin),
                (unsigned long long)st_sec[0], (unsigned long long)st_sec[1], (unsigned long long)st_sec[2], (unsigned long long)st_sec[3], (unsigned long long)st_sec[4], (unsigned long long)st_sec[5]);
+        printf("round parts: stage+window %llu lit lut+deep %llu match %llu\n", (unsigned long long)st_sec[6], (unsigned long long)st_sec[7], (unsigned long long)st_sec[0]);
         printf("bump: open %llu count %llu mid %llu add %llu count-iters %llu\n", g_st[0], g_st[1], g_st[2], g_st[3], g_st[4]);
         printf("lit slow: insert %u/%llu changed %u/%llu lut %u/%llu; pos: insert %u/%llu changed %u/%llu lut %u/%llu\n",
                lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1], lit.st_cnt[2], (unsigned long long)lit.st_cyc[2],
