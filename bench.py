@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU")
     ap.add_argument("--block-bytes", type=int, default=262144)
     ap.add_argument("--win-bits", type=int, default=15)
-    ap.add_argument("--cpu-blocks", type=int, default=2, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-blocks", type=int, default=4, help="CPU baseline sample: about 13 s of one host core (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--finder", choices=["index", "scan"], default="index",
                     help="stage-1 match finder: index (default) or the brute-force scan")
