@@ -799,32 +799,50 @@ __device__ __noinline__ uint32_t slow_changed(uint64_t* link, uint32_t* freq, Tr
 
 // decoder: table over the next kLutBits stream bits -> (node reached, bits used).
 // Entry = node | used << 10; a missing child gives node = kNil.
+// One step of the table build: the entry for a prefix one bit longer than `parent`'s.
+// A finished entry (leaf, or a missing child) is inherited; an internal node hands
+// down the child the new bit selects, with one more bit used.
+template <class T>
+__device__ __forceinline__ uint32_t lut_descend(const uint64_t* link, uint32_t parent, int bit, int level) {
+    const uint32_t node = parent & 0x3FFu;
+    const bool inside = node != kNil && node >= (uint32_t)T::kRoot;
+    const uint32_t kids = (uint32_t)(link[inside ? (int)node : (int)T::kRoot] >> 32);
+    const uint32_t child = (kids >> (bit ? 10 : 0)) & 0x3FFu;
+    return inside ? (child | ((uint32_t)level << 10)) : parent;
+}
+
 template <class T>
 __device__ __noinline__ void slow_build_lut(const uint64_t* link, uint16_t* lut, int lane) {
-    // every lane follows its table entries down the tree together, one level per
-    // round trip (the walks are independent, so their reads overlap)
-    constexpr int kPer = (1 << T::kLutBits) / kWave > 0 ? (1 << T::kLutBits) / kWave : 1;
-    int node[kPer], used[kPer];
+    // level by level from the root: the table for (L+1)-bit prefixes follows from the one
+    // for L-bit prefixes with one link read per entry, 2^(L+1) entries per level instead
+    // of a root walk per final entry.  Lane j holds entry j while a level fits the wave.
+    static_assert(T::kLutBits == 6 || T::kLutBits == 8, "table widths the decoder uses");
+    const int half = (lane >> 1) * 4;                         // byte address of lane j>>1
+    const int bit = lane & 1;
+    uint32_t e = (uint32_t)T::kRoot;                          // the 0-bit prefix: root, no bits used
 #pragma unroll
-    for (int e = 0; e < kPer; e++) { node[e] = T::kRoot; used[e] = 0; }
-#pragma unroll 1
-    for (int level = 0; level < T::kLutBits; level++) {
-#pragma unroll
-        for (int e = 0; e < kPer; e++) {
-            const int idx = e * kWave + lane;
-            const bool inside = node[e] != (int)kNil && node[e] >= (int)T::kRoot;
-            const uint32_t kids = (uint32_t)(link[inside ? node[e] : (int)T::kRoot] >> 32);
-            const int bit = (idx >> (T::kLutBits - 1 - level)) & 1;
-            const int child = (int)((kids >> (bit ? 10 : 0)) & 0x3FFu);
-            node[e] = inside ? child : node[e];
-            used[e] += inside ? 1 : 0;
-        }
+    for (int level = 1; level <= 6; level++) {
+        const uint32_t parent = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)e);
+        e = lut_descend<T>(link, parent, bit, level);
     }
-#pragma unroll
-    for (int e = 0; e < kPer; e++) {
-        const int idx = e * kWave + lane;
-        if (idx < (1 << T::kLutBits)) { lut[idx] = (uint16_t)(node[e] | (used[e] << 10)); }
+    if (T::kLutBits == 6) {
+        lut[lane] = (uint16_t)e;
+        return;
     }
+    // 128 entries: j and j + 64 descend from entries j>>1 and 32 + (j>>1) of level 6
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)e);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)e);
+    const uint32_t r0 = lut_descend<T>(link, p0, bit, 7);
+    const uint32_t r1 = lut_descend<T>(link, p1, bit, 7);
+    // 256 entries: j + 64k descends from entry 32k + (j>>1) of level 7 (r0: 0..63, r1: 64..127)
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)r0);
+    const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)r0);
+    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)r1);
+    const uint32_t q3 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)r1);
+    lut[lane]       = (uint16_t)lut_descend<T>(link, q0, bit, 8);
+    lut[lane + 64]  = (uint16_t)lut_descend<T>(link, q1, bit, 8);
+    lut[lane + 128] = (uint16_t)lut_descend<T>(link, q2, bit, 8);
+    lut[lane + 192] = (uint16_t)lut_descend<T>(link, q3, bit, 8);
 }
 
 constexpr int kLitLeaves = 288;               // symbols 0..285 (+2 pad)
