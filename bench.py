@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU")
     ap.add_argument("--block-bytes", type=int, default=262144)
     ap.add_argument("--win-bits", type=int, default=15)
-    ap.add_argument("--cpu-blocks", type=int, default=4, help="CPU baseline sample: about 13 s of one host core (0 = skip)")
+    ap.add_argument("--cpu-blocks", type=int, default=8, help="CPU baseline sample: blocks 0..7 (SURVEY.md 8d), about 26 s of one host core (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--finder", choices=["index", "scan"], default="index",
                     help="stage-1 match finder: index (default) or the brute-force scan")
@@ -138,6 +138,17 @@ def main():
     tim = batch.get_timing(reset=True)
     batch.set_timing(False)
     assert int(err.abs().sum()) == 0, "encode reported errors"
+    # ---- secondary bound: what the serial stages actually chew through.
+    # tok_count[n] is the head of the encode scratch (include/sqz/sqz.h); block 0's token
+    # words follow at the 256-byte-aligned offset.  Not timed.
+    tok_counts = enc.scratch[:4 * n].view(torch.int32)
+    tokens_rank = int(tok_counts.to(torch.int64).sum())
+    head = (4 * n + 255) // 256 * 256
+    t0c = int(tok_counts[0])
+    tw = enc.scratch[head:head + 4 * t0c].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    tlen = torch.where((tw >> 31) != 0, (tw >> 16) & 0x1FF, torch.ones_like(tw))
+    tpos = torch.cumsum(tlen, 0) - tlen                      # start position of every token
+    cand0 = int(torch.clamp(tpos, max=(1 << wb) - 1).sum())  # scan: min(i, window-1) candidates per token
     comp_bytes = int(out_bytes.sum().item())
 
     # ---- decode: same K / W ----------------------------------------------------
@@ -160,8 +171,10 @@ def main():
         enc_s = shard.max_over_ranks(enc_s, red_dev)
         dec_s = shard.max_over_ranks(dec_s, red_dev)
         comp_total = shard.sum_over_ranks(float(comp_bytes), red_dev)
+        tokens_all = int(shard.sum_over_ranks(float(tokens_rank), red_dev))
     else:
         comp_total = float(comp_bytes)
+        tokens_all = tokens_rank
 
     if rank == 0:
         in_total = float(world) * n * bb
@@ -200,6 +213,20 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "encode_frac_of_hbm_roof": round(
                              algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 7)},
+        }
+        serial_ms = sum(enc_k.get(k, 0.0) for k in ("index_parse_kernel", "huffman_emit_kernel"))
+        line["secondary"] = {
+            "note": "the path is a serial chain per stream, not HBM-bound: tokens through the "
+                    "adaptive-Huffman stage per second, and the candidate tests the reference's "
+                    "O(window) scan makes for the same tokens (block 0 x blocks; the indexed finder "
+                    "visits only equal-prefix candidates, --finder scan performs them all)",
+            "tokens_per_step": tokens_all,
+            "tokens_per_s_encode": round(tokens_all / (ms_per_step * 1e-3), 1),
+            "tokens_per_s_emit_kernel": round(tokens_rank / (enc_k["huffman_emit_kernel"] * 1e-3), 1),
+            "tokens_per_s_entropy_decode_kernel": round(tokens_rank / (dec_k["entropy_decode_kernel"] * 1e-3), 1),
+            "scan_candidate_tests_per_step": cand0 * n * world,
+            "scan_candidate_tests_per_s": round(cand0 * n * world / (ms_per_step * 1e-3), 1),
+            "serial_stage_ms": round(serial_ms, 3),
         }
         if world == 1 and args.cpu_blocks > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_blocks, bb, wb)

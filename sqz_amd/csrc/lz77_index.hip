@@ -254,12 +254,24 @@ void index_match_kernel(const uint8_t* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kParseStrip = 512;
+// Greedy parse (squeeze.h:377-394) over the match table, without the serial walk.
+// Token starts are the positions reachable from 0 through next(i) = i + (match ? len : 1).
+// A tile of 64 chunks is staged in LDS; lane l first walks chunk l from its first position
+// on its own (a guess: the real way in is not known yet).  Two walks that ever land on the
+// same position are the same from there on, so the real path through a chunk -- entered
+// where the previous chunk's path left -- only has to be followed until it steps on a
+// position the guess also visited; from there the guess is right.  That fix-up runs chunk
+// by chunk, a few hops each, instead of one hop per token.
+constexpr int kChunk = 64;                          // positions per lane
+constexpr int kTile = kChunk * kWave;               // positions per pass
+constexpr int kChunkRow = kChunk + 1;               // padded: same-offset reads of all lanes spread over the banks
 
 struct ParseLds {
-    uint32_t m[kParseStrip];
-    __attribute__((aligned(4))) uint8_t d[kParseStrip];
+    uint32_t m[kChunkRow * kWave];                  // match word per position (0 = literal)
+    __attribute__((aligned(4))) uint8_t d[kTile];   // the bytes (literal tokens)
 };
+
+__device__ __forceinline__ uint32_t parse_slot(uint32_t k) { return k + (k / (uint32_t)kChunk); }
 
 __global__ __launch_bounds__(kWave)
 void index_parse_kernel(const uint8_t* __restrict__ in,
@@ -277,37 +289,83 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
     const uint32_t* M = match + in_off[b];
     uint32_t* tok = tokens + in_off[b];
 
-    uint64_t i = 0, sbase = 0;
-    uint32_t have = 0;                  // strip covers [sbase, sbase + have)
-    uint32_t ntok = 0, tok_reg = 0;
-    while (i < bytes) {
-        if (i >= sbase + have) {        // (re)load the strip at i
-            sbase = i;
-            const uint64_t left = bytes - sbase;
-            have = left < (uint64_t)kParseStrip ? (uint32_t)left : (uint32_t)kParseStrip;
-            __syncthreads();
-            for (uint32_t k = lane; k < have; k += kWave) {
-                // positions bytes-2, bytes-1 have no 3-byte prefix: literal
-                lds.m[k] = (sbase + k + 2 < bytes) ? M[sbase + k] : 0u;
-                lds.d[k] = src[sbase + k];
+    uint32_t ntok = 0;
+    uint32_t entry = 0;                              // where the real path enters the tile (tile-relative)
+    for (uint64_t tile = 0; tile < bytes; tile += (uint64_t)kTile) {
+        const uint64_t left = bytes - tile;
+        const uint32_t have = left < (uint64_t)kTile ? (uint32_t)left : (uint32_t)kTile;
+        if (entry >= have) { entry -= (uint32_t)kTile; continue; }         // a token spans the whole tile
+        __syncthreads();
+        for (uint32_t k = lane; k < have; k += kWave) {
+            // positions bytes-2, bytes-1 have no 3-byte prefix: literal
+            lds.m[parse_slot(k)] = (tile + k + 2 < bytes) ? M[tile + k] : 0u;
+        }
+        for (uint32_t k = 4u * lane; k < have; k += 4u * kWave) {
+            uint32_t v = 0;
+            if (k + 4 <= have && ((reinterpret_cast<uintptr_t>(src + tile + k) & 3u) == 0)) {
+                v = *reinterpret_cast<const uint32_t*>(src + tile + k);
+            } else {
+                for (uint32_t j = 0; j < 4 && k + j < have; j++) { v |= (uint32_t)src[tile + k + j] << (8 * j); }
             }
-            __syncthreads();
+            *reinterpret_cast<uint32_t*>(&lds.d[k]) = v;
         }
-        const uint32_t at = (uint32_t)(i - sbase);
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.m[at]);
-        uint32_t word;
-        if (m != 0) {
-            word = kTokMatch | m;
-            i += m >> 16;
-        } else {
-            word = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.d[at]);
-            i += 1;
+        __syncthreads();
+
+        // ---- every lane: its chunk from the chunk's first position ---------------------
+        const uint32_t lo = (uint32_t)lane * (uint32_t)kChunk;
+        const uint32_t room = have > lo ? (have - lo < (uint32_t)kChunk ? have - lo : (uint32_t)kChunk) : 0u;
+        const uint32_t* row = &lds.m[lane * kChunkRow];
+        uint64_t guess = 0;
+        uint32_t p = 0;
+        while (p < room) {
+            guess |= 1ull << p;
+            const uint32_t w = row[p];
+            p += w != 0 ? (w >> 16) : 1u;
         }
-        if ((uint32_t)lane == (ntok & 63u)) { tok_reg = word; }
-        ntok++;
-        if ((ntok & 63u) == 0) { tok[ntok - 64 + lane] = tok_reg; }
+        const uint32_t guess_out = lo + p;           // where the guess leaves the chunk (>= lo + room)
+
+        // ---- the real path, chunk by chunk (uniform) -----------------------------------
+        uint64_t mine = 0;                           // this lane's chunk: real token starts
+        uint32_t e = entry;
+        for (int l = 0; l < kWave; l++) {
+            const uint32_t clo = (uint32_t)l * (uint32_t)kChunk;
+            if (clo >= have) { break; }
+            const uint32_t chi = clo + (uint32_t)kChunk < have ? clo + (uint32_t)kChunk : have;
+            if (e >= chi) { continue; }              // the path jumps over this chunk
+            const uint64_t g = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(guess >> 32), l) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)guess, l);
+            const uint32_t gout = (uint32_t)__builtin_amdgcn_readlane((int)guess_out, l);
+            uint64_t real = 0;
+            uint32_t q = e - clo;
+            const uint32_t croom = chi - clo;
+            for (;;) {
+                if ((g >> q) & 1ull) {               // the guess was here too: the rest is the guess's
+                    real |= g & ~((1ull << q) - 1ull);
+                    e = gout;
+                    break;
+                }
+                real |= 1ull << q;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.m[l * kChunkRow + (int)q]);
+                q += w != 0 ? (w >> 16) : 1u;
+                if (q >= croom) { e = clo + q; break; }
+            }
+            if (lane == l) { mine = real; }
+        }
+        entry = e - (uint32_t)kTile;                 // e >= have here; carried into the next tile
+
+        // ---- token words, in order ----------------------------------------------------
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(mine);
+        const uint32_t incl = wave_scan(cnt);
+        uint32_t at = ntok + incl - cnt;
+        uint64_t bits = mine;
+        while (bits != 0) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const uint32_t w = row[k];
+            tok[at++] = w != 0 ? (kTokMatch | w) : (uint32_t)lds.d[lo + k];
+        }
+        ntok += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
     }
-    if ((uint32_t)lane < (ntok & 63u)) { tok[(ntok & ~63u) + lane] = tok_reg; }
     if (lane == 0) { tok_count[b] = ntok; }
 }
 
