@@ -28,6 +28,7 @@
 
 namespace sqzk {
 
+constexpr int kXcds = 8;                 // MI355X: 8 XCDs, workgroups dispatched round-robin over them
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
 
@@ -206,11 +207,17 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                         uint32_t n_blocks, uint32_t window,
                         const uint32_t* __restrict__ sorted,
                         uint32_t* __restrict__ match, uint32_t groups) {
-    // consecutive workgroups share a stream, so its bytes and its sorted positions stay
-    // in the L2s while they are gathered at random (with the stream on the fast grid axis
-    // this kernel pulled 185 GB across the fabric for a 1 GiB batch)
-    const uint32_t b = blockIdx.x / groups;
-    const uint32_t group = blockIdx.x % groups;
+    // A stream's workgroups all run on ONE XCD, one stream after the other: workgroup k is
+    // dispatched to XCD k % 8, so stream b = 8 * (k / 8 / groups) + k % 8.  Its bytes, sorted
+    // positions and match words (~2.3 MB for 256 KB) then live in that XCD's 4 MB L2 while
+    // they are gathered and scattered at random, and the 4-byte scatter into match[] merges
+    // into full lines there instead of leaving as partial-line writes (with the stream on
+    // the fast grid axis this kernel pulled 185 GB across the fabric for a 1 GiB batch; with
+    // a stream spread over all eight L2s it still wrote 42 GB for 4 GB of match words).
+    const uint32_t xcd = blockIdx.x % (uint32_t)kXcds;
+    const uint32_t local = blockIdx.x / (uint32_t)kXcds;
+    const uint32_t b = (local / groups) * (uint32_t)kXcds + xcd;
+    const uint32_t group = local % groups;
     if (b >= n_blocks) { return; }
     const uint8_t* src = in + in_off[b];
     const uint64_t bytes = in_off[b + 1] - in_off[b];
@@ -381,8 +388,9 @@ void launch_index_match(const uint8_t* in, const uint64_t* in_off, uint32_t n_bl
                         uint32_t match_groups, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     if (match_groups < 1) { match_groups = 1; }
-    while ((uint64_t)match_groups * n_blocks > 0x7FFFFFFFull) { match_groups = (match_groups + 1) / 2; }
-    hipLaunchKernelGGL(index_match_kernel, dim3(n_blocks * match_groups), dim3(256), 0, stream,
+    const uint32_t rounded = (n_blocks + (uint32_t)kXcds - 1) / (uint32_t)kXcds * (uint32_t)kXcds;
+    while ((uint64_t)match_groups * rounded > 0x7FFFFFFFull) { match_groups = (match_groups + 1) / 2; }
+    hipLaunchKernelGGL(index_match_kernel, dim3(rounded * match_groups), dim3(256), 0, stream,
                        in, in_off, n_blocks, window, sorted, match, match_groups);
 }
 
