@@ -32,10 +32,24 @@ constexpr int kXcds = 8;                 // MI355X: 8 XCDs, workgroups dispatche
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
 
+constexpr int kSortTile = 4 * kSortThreads;      // elements per workgroup tile (4 rows of 64 per wave)
+
+// One pass = a histogram sweep (global digit bases) and a scatter sweep.  The scatter does
+// not write elements where they fall: every 4096-element tile is first ordered by digit in
+// LDS (stable: wave order, then row and lane order inside a wave), then copied out, so a
+// digit's elements of one tile leave as one contiguous run (16 elements = one line on
+// average, far longer for the frequent digits).  Writing each element straight to its
+// bucket kept ~256 half-filled lines open per wave -- 16 MB of open lines per XCD against
+// 4 MB of L2 -- and they left as partial-line writes: 53 GB written for 12 GB of elements.
 struct SortLds {
-    uint32_t cnt[kSortWaves][256];   // per wave, per digit: running destination
+    uint32_t elem[kSortTile];            // the tile in digit order; the histogram sweep's counters alias it
+    uint8_t  dig[kSortTile];             // digit per tile slot
+    uint16_t cnt[kSortWaves][256];       // per tile: elements of (wave, digit) so far -> offset inside the digit's run
+    uint32_t gbase[256];                 // where the next tile's run of digit d goes
+    uint32_t tstart[256];                // tile slot where digit d's run starts
     uint32_t total[256];
 };
+static_assert(sizeof(uint32_t) * kSortTile >= sizeof(uint32_t) * kSortWaves * 256, "histogram counters alias elem[]");
 
 struct __attribute__((packed)) U32u { uint32_t v; };
 
@@ -84,62 +98,65 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
     // blocks up to 16 MB carry byte 0 of the key in the element's top 8 bits from
     // pass 1 to pass 2, so only pass 1 gathers at random
     const bool carry = bytes <= (1u << 24);
-
-    // each wave owns a contiguous slice (keeps the scatter stable without
-    // workgroup barriers inside the sweep)
-    const uint32_t slice = (((count + kSortWaves - 1) / kSortWaves) + 63u) & ~63u;
-    const uint32_t lo = (uint32_t)wave * slice < count ? (uint32_t)wave * slice : count;
-    const uint32_t hi = lo + slice < count ? lo + slice : count;
+    uint32_t (*const hist)[256] = reinterpret_cast<uint32_t (*)[256]>(lds.elem);
 
     for (int pass = 0; pass < 3; pass++) {
         // pass 0: identity -> A by byte 2 ; pass 1: A -> B by byte 1 ; pass 2: B -> A by byte 0
         const uint32_t* from = pass == 1 ? pa : pb;
         uint32_t* to = pass == 1 ? pb : pa;
-        const int byte_ix = 2 - pass;
 
-        for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
-        // ---- count (4 rows of 64 per trip: the dependent global loads overlap) ----
-        for (uint32_t e = lo; e < hi; e += 4 * kWave) {
-            uint32_t pos[4], digit[4];
-            bool valid[4];
+        // element k of the input order belongs to tile k / 4096, wave (k / 256) % 16, row (k / 64) % 4:
+        // both sweeps use this mapping, so a thread meets the same elements twice
+        auto load_rows = [&](uint32_t tile, bool first, uint32_t (&elem)[4], uint32_t (&digit)[4], bool (&valid)[4]) {
+            uint32_t pos[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t k = e + (uint32_t)(j * kWave + lane);
-                valid[j] = k < hi;
+                const uint32_t k = tile + (uint32_t)(wave * 256 + j * kWave + lane);
+                valid[j] = k < count;
                 pos[j] = valid[j] ? (pass == 0 ? k : from[k]) : 0u;
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t k = e + (uint32_t)(j * kWave + lane);
-                digit[j] = 0;
+                const uint32_t k = tile + (uint32_t)(wave * 256 + j * kWave + lane);
+                digit[j] = 0; elem[j] = pos[j];
                 if (valid[j]) {
                     if (pass == 0) { digit[j] = src[pos[j] + 2]; }
-                    else if (pass == 1) {          // the one random gather: bytes p and p+1
-                        const uint32_t w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
-                        cache[k] = (uint16_t)w;
+                    else if (pass == 1) {
+                        uint32_t w;
+                        if (first) {                   // the one random gather: bytes p and p+1
+                            w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
+                            cache[k] = (uint16_t)w;
+                        } else {
+                            w = cache[k];              // written by this thread in the histogram sweep
+                        }
                         digit[j] = w >> 8;
+                        if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
                     } else {
                         digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
+                        if (carry) { elem[j] = pos[j] & 0x00FFFFFFu; }
                     }
                 }
             }
+        };
+
+        // ---- histogram of the whole stream (wave-private counters, no atomics) --------
+        for (int d = lane; d < 256; d += kWave) { hist[wave][d] = 0; }
+        for (uint32_t tile = 0; tile < count; tile += (uint32_t)kSortTile) {
+            uint32_t elem[4], digit[4];
+            bool valid[4];
+            load_rows(tile, true, elem, digit, valid);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint64_t peers = peers_of(digit[j], valid[j]);
                 if (valid[j] && lanes_below(peers) == 0) {
-                    lds.cnt[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
+                    hist[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
                 }
             }
         }
         __syncthreads();
-        // ---- offsets: digit-major, then wave order inside a digit -------------
         if (tid < 256) {
             uint32_t run = 0;
-            for (int w = 0; w < kSortWaves; w++) {
-                const uint32_t c = lds.cnt[w][tid];
-                lds.cnt[w][tid] = run;
-                run += c;
-            }
+            for (int w = 0; w < kSortWaves; w++) { run += hist[w][tid]; }
             lds.total[tid] = run;
         }
         __syncthreads();
@@ -151,48 +168,72 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
             incl = wave_scan(incl);
             uint32_t excl = incl - s;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { lds.total[4 * lane + j] = excl; excl += v[j]; }
+            for (int j = 0; j < 4; j++) { lds.gbase[4 * lane + j] = excl; excl += v[j]; }
         }
         __syncthreads();
-        for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] += lds.total[d]; }
-        // ---- stable scatter (wave-private counters: no barrier needed) -------
-        for (uint32_t e = lo; e < hi; e += 4 * kWave) {
-            uint32_t pos[4], digit[4], elem[4];
+
+        // ---- scatter, tile by tile ------------------------------------------------------
+        for (uint32_t tile = 0; tile < count; tile += (uint32_t)kSortTile) {
+            const uint32_t n_tile = count - tile < (uint32_t)kSortTile ? count - tile : (uint32_t)kSortTile;
+            for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
+            uint32_t elem[4], digit[4], wrank[4];
             bool valid[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t k = e + (uint32_t)(j * kWave + lane);
-                valid[j] = k < hi;
-                pos[j] = valid[j] ? (pass == 0 ? k : from[k]) : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t k = e + (uint32_t)(j * kWave + lane);
-                digit[j] = 0; elem[j] = pos[j];
-                if (valid[j]) {
-                    if (pass == 0) { digit[j] = src[pos[j] + 2]; }
-                    else if (pass == 1) {
-                        const uint32_t w = cache[k];           // written by this lane in the count sweep
-                        digit[j] = w >> 8;
-                        if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
-                    } else {
-                        digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
-                        if (carry) { elem[j] = pos[j] & 0x00FFFFFFu; }
-                    }
-                }
-            }
+            load_rows(tile, false, elem, digit, valid);
 #pragma unroll
             for (int j = 0; j < 4; j++) {                      // rows in order: stability
                 const uint64_t peers = peers_of(digit[j], valid[j]);
                 const uint32_t rank = lanes_below(peers);
-                uint32_t dest = 0;
-                if (valid[j]) { dest = lds.cnt[wave][digit[j]] + rank; }
+                wrank[j] = valid[j] ? (uint32_t)lds.cnt[wave][digit[j]] + rank : 0u;
                 __builtin_amdgcn_wave_barrier();               // all reads before the leaders' writes
                 if (valid[j] && rank == 0) {
-                    lds.cnt[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
+                    lds.cnt[wave][digit[j]] = (uint16_t)(lds.cnt[wave][digit[j]] + (uint32_t)__builtin_popcountll(peers));
                 }
-                if (valid[j]) { to[dest] = elem[j]; }
+                __builtin_amdgcn_wave_barrier();
             }
+            __syncthreads();
+            uint32_t tcount = 0;
+            if (tid < 256) {                                   // offsets of the waves inside a digit's run
+                for (int w = 0; w < kSortWaves; w++) {
+                    const uint32_t c = lds.cnt[w][tid];
+                    lds.cnt[w][tid] = (uint16_t)tcount;
+                    tcount += c;
+                }
+                lds.total[tid] = tcount;
+            }
+            __syncthreads();
+            if (wave == 0) {                                   // where each digit's run starts in the tile
+                uint32_t v[4], s = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = lds.total[4 * lane + j]; s += v[j]; }
+                uint32_t incl = s;
+                incl = wave_scan(incl);
+                uint32_t excl = incl - s;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { lds.tstart[4 * lane + j] = excl; excl += v[j]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (valid[j]) {
+                    const uint32_t slot = lds.tstart[digit[j]] + (uint32_t)lds.cnt[wave][digit[j]] + wrank[j];
+                    if (slot < (uint32_t)kSortTile) {          // always: slots are a permutation of [0, n_tile)
+                        lds.elem[slot] = elem[j];
+                        lds.dig[slot] = (uint8_t)digit[j];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {                      // runs leave contiguously
+                const uint32_t slot = (uint32_t)(j * kSortThreads + tid);
+                if (slot < n_tile) {
+                    const uint32_t d = lds.dig[slot];
+                    const uint32_t dest = lds.gbase[d] + (slot - lds.tstart[d]);
+                    if (dest < count) { to[dest] = lds.elem[slot]; }   // always: a permutation of [0, count)
+                }
+            }
+            __syncthreads();
+            if (tid < 256) { lds.gbase[tid] += tcount; }
         }
         // the next pass reads what other waves of this workgroup wrote
         __threadfence_block();
