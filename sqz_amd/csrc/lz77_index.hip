@@ -249,12 +249,12 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                         const uint32_t* __restrict__ sorted,
                         uint32_t* __restrict__ match, uint32_t groups) {
     // A stream's workgroups all run on ONE XCD, one stream after the other: workgroup k is
-    // dispatched to XCD k % 8, so stream b = 8 * (k / 8 / groups) + k % 8.  Its bytes, sorted
-    // positions and match words (~2.3 MB for 256 KB) then live in that XCD's 4 MB L2 while
-    // they are gathered and scattered at random, and the 4-byte scatter into match[] merges
-    // into full lines there instead of leaving as partial-line writes (with the stream on
-    // the fast grid axis this kernel pulled 185 GB across the fabric for a 1 GiB batch; with
-    // a stream spread over all eight L2s it still wrote 42 GB for 4 GB of match words).
+    // dispatched to XCD k % 8, so stream b = 8 * (k / 8 / groups) + k % 8.  Its bytes and
+    // sorted positions (~1.3 MB for 256 KB) then stay in that XCD's 4 MB L2 while they are
+    // gathered at random.  Measured (PMC, 1 GiB batch): FETCH 185 GB with the stream on the
+    // fast grid axis, 16.3 GB with consecutive workgroups sharing a stream across all eight
+    // L2s, 3.5 GB with this mapping (61 -> 38 ms).  The 4-byte scatter into match[] is NOT
+    // helped by it: WRITE_SIZE stayed at 41-47 GB for 4 GB of match words (open item).
     const uint32_t xcd = blockIdx.x % (uint32_t)kXcds;
     const uint32_t local = blockIdx.x / (uint32_t)kXcds;
     const uint32_t b = (local / groups) * (uint32_t)kXcds + xcd;
