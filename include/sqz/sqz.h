@@ -133,6 +133,17 @@ SQZ_API extern squeeze_interface squeeze;
 /* worst-case compressed size of one block of `bytes` bytes (multiple of 8) */
 SQZ_API uint64_t sqz_bound(uint64_t bytes);
 
+/* File-mode bit streams (attic/map_experiment/test.c:39-42,98-101; bitstream.h `.stream`,
+ * `.output`, `.input`): the reference hands every 64-bit word of the stream to
+ * fwrite(&b64, 8, 1, f) / fread(&b64, 8, 1, f), i.e. in HOST byte order, while a memory-mode
+ * stream holds the words most-significant byte first.  This converts one image into the
+ * other (the operation is its own inverse; on a big-endian host it is a copy): write
+ * out[] with fwrite to get the file the reference's harness writes, or pass a file's bytes
+ * through it to get the stream sqz_decompress / sqz_decode_blocks read.  `bytes` must be a
+ * multiple of 8 (every stream is, bitstream.h:112-114); in == out is allowed.
+ * Returns 0 or EINVAL.  Host code: no device is touched.                              */
+SQZ_API int sqz_file_words(const uint8_t* in, uint64_t bytes, uint8_t* out);
+
 /* host buffers in, host buffers out (H2D + kernels + D2H inside) */
 SQZ_API int sqz_encode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
                               uint32_t window,

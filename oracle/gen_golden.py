@@ -37,6 +37,8 @@ CORPUS = ["laozi.txt", "confucius.txt", "mandrill.bmp", "arm64.elf", "x64.elf",
 REF = ctypes.CDLL(os.path.join(HERE, "_ref", "libsqz_ref.so"))
 ORA = ctypes.CDLL(os.path.join(HERE, "liboracle.so"))
 REF.sqz_ref_compress.restype = ctypes.c_int64
+REF.sqz_ref_compress_file.restype = ctypes.c_int64
+REF.sqz_ref_compress_file.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p]
 REF.sqz_ref_compress.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64]
 ORA.sqzo_fnv1a64.restype = ctypes.c_uint64
@@ -115,6 +117,16 @@ def main():
             if f in ("laozi.txt", "confucius.txt"):
                 with open(os.path.join(GOLD, f"{f}.w{wb}.sqz"), "wb") as fh:
                     fh.write(out)
+            if f == "laozi.txt":
+                # the same stream as the reference's FILE mode writes it (attic test.c:39-42):
+                # produced by the reference's own .output callback path, not by swapping here
+                path = os.path.join(GOLD, f"{f}.w{wb}.file")
+                n = REF.sqz_ref_compress_file(data, len(data), wb, path.encode())
+                assert n == len(out), (n, len(out))
+                gold.setdefault("file_mode", []).append(
+                    {"file": f, "win_bits": wb, "image": os.path.basename(path),
+                     "stream": f"{f}.w{wb}.sqz", "bytes": int(n),
+                     "image_fnv": fnv(open(path, "rb").read())})
             print(f, wb, len(out), fnv(out), flush=True)
 
     # Zipf blocks: full size at 2^15 (slow: ~8 s each) and small ones

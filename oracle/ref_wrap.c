@@ -12,7 +12,7 @@
  *
  * Exposed C ABI (used by tests/ and oracle/gen_golden.py only):
  *   sqz_ref_compress / sqz_ref_decompress / sqz_ref_available /
- *   sqz_ref_tree_run
+ *   sqz_ref_tree_run / sqz_ref_compress_file / sqz_ref_decompress_file
  */
 #include <stdbool.h>
 #include <stdint.h>
@@ -65,6 +65,65 @@ int sqz_ref_decompress(const uint8_t* in, uint64_t in_bytes, int with_header,
     int r = s->error;
     squeeze.free(s);
     *bytes_io = bytes;
+    return r;
+}
+
+/* The reference's FILE mode (attic test.c:39-42, 98-101): the bit stream hands every
+ * full 64-bit word to a callback that fwrite()s / fread()s `b64` in HOST byte order
+ * (bitstream.h: `.stream`, `.output`, `.input`).  These two drive exactly that path of
+ * the reference, so the file image -- which differs from the memory-mode bytes on a
+ * little-endian host -- is pinned by the reference itself, not by a reading of it. */
+static int ref_write_file(bitstream* bs) {
+    return fwrite(&bs->b64, 8, 1, (FILE*)bs->stream) == 1 ? 0 : (errno != 0 ? errno : EIO);
+}
+
+static int ref_read_file(bitstream* bs) {
+    return fread(&bs->b64, 8, 1, (FILE*)bs->stream) == 1 ? 0 : (errno != 0 ? errno : EIO);
+}
+
+/* header + payload into `path`; returns bytes written (>=0) or -errno */
+int64_t sqz_ref_compress_file(const uint8_t* data, uint64_t bytes, int win_bits, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (f == NULL) { return -(int64_t)errno; }
+    bitstream bs = { .stream = f, .output = ref_write_file };
+    squeeze.write_header(&bs, bytes, (uint8_t)win_bits);
+    int64_t r = bs.error != 0 ? -(int64_t)bs.error : 0;
+    if (r == 0) {
+        squeeze_type* s = squeeze.alloc(0);
+        if (s == NULL) { r = -(int64_t)ENOMEM; }
+        else {
+            squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << win_bits));
+            r = s->error != 0 ? -(int64_t)s->error : (int64_t)bs.bytes;
+            squeeze.free(s);
+        }
+    }
+    if (fclose(f) != 0 && r >= 0) { r = -(int64_t)errno; }
+    return r;
+}
+
+/* reads `path` through the reference's `.input` callback; returns 0 or errno */
+int sqz_ref_decompress_file(const char* path, uint8_t* data, uint64_t capacity,
+                            uint64_t* bytes_out, int* win_bits_out) {
+    FILE* f = fopen(path, "rb");
+    if (f == NULL) { return errno; }
+    bitstream bs = { .stream = f, .input = ref_read_file };
+    uint64_t bytes = 0;
+    uint8_t win_bits = 0;
+    squeeze.read_header(&bs, &bytes, &win_bits);
+    int r = bs.error;
+    if (r == 0 && bytes > capacity) { r = E2BIG; }
+    if (r == 0) {
+        squeeze_type* s = squeeze.alloc(0);
+        if (s == NULL) { r = ENOMEM; }
+        else {
+            squeeze.decompress(s, &bs, data, bytes);
+            r = s->error;
+            squeeze.free(s);
+        }
+    }
+    fclose(f);
+    if (bytes_out) { *bytes_out = bytes; }
+    if (win_bits_out) { *win_bits_out = win_bits; }
     return r;
 }
 

@@ -6,7 +6,7 @@ a mirror of the reference's codec interface, the device-resident batch path and
 the multi-GPU block sharding.
 """
 from .codec import (SqzError, bound, compress, decompress, device_info,  # noqa: F401
-                    MIN_WIN_BITS, MAX_WIN_BITS)
+                    file_words, MIN_WIN_BITS, MAX_WIN_BITS)
 
-__all__ = ["SqzError", "bound", "compress", "decompress", "device_info",
+__all__ = ["SqzError", "bound", "compress", "decompress", "device_info", "file_words",
            "MIN_WIN_BITS", "MAX_WIN_BITS"]

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "sqz_version": (C.c_char_p, []),
     "sqz_hip_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
     "sqz_bound": (C.c_uint64, [C.c_uint64]),
+    "sqz_file_words": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "sqz_init": (None, [C.POINTER(Sqz)]),
     "sqz_write_header": (None, [C.POINTER(Bitstream), C.c_uint64]),
     "sqz_read_header": (None, [C.POINTER(Bitstream), _u64p]),

@@ -28,6 +28,17 @@ def bound(nbytes: int) -> int:
     return int(N.lib().sqz_bound(nbytes))
 
 
+def file_words(stream) -> bytes:
+    """Memory-mode stream <-> the byte image of a file written by the reference's file mode
+    (attic test.c:39-42: fwrite(&b64, 8, 1, f) in host byte order).  Its own inverse."""
+    stream = bytes(stream)
+    out = C.create_string_buffer(len(stream))
+    rc = N.lib().sqz_file_words(stream, len(stream), out)
+    if rc != 0:
+        _raise(rc, "sqz_file_words")
+    return out.raw
+
+
 def compress(data, win_bits: int = 15, header: bool = True, capacity: int = None,
              window: int = None) -> bytes:
     """attic test.c:44-96 in memory: [write_header] + compress -> bytes.

@@ -341,6 +341,16 @@ int sqz_hip_device_info(char* name, size_t name_cap, int* compute_units,
 
 uint64_t sqz_bound(uint64_t bytes) { return (2 * bytes + 1024 + 7) & ~(uint64_t)7; }
 
+int sqz_file_words(const uint8_t* in, uint64_t bytes, uint8_t* out) {
+    if ((bytes & 7u) != 0 || (bytes != 0 && (in == NULL || out == NULL))) { return EINVAL; }
+    for (uint64_t k = 0; k < bytes; k += 8) {
+        uint64_t w = 0;                                   // the word's value: stream bytes are MSB first
+        for (int j = 0; j < 8; j++) { w = (w << 8) | in[k + j]; }
+        memcpy(out + k, &w, 8);                           // what fwrite(&b64, 8, 1, f) puts in the file
+    }
+    return 0;
+}
+
 void sqz_init(struct sqz* s) {
     if (s == NULL) { return; }
     memset(s, 0, sizeof(*s));

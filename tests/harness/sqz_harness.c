@@ -9,19 +9,26 @@
  * skipped like file_exist() does, test.c:231).  The reference harness itself needs the
  * MSVC CRT (fopen_s, errno_t) and does not build on Linux.
  *
- * Differences: the reference streams 8-byte words to a FILE through a callback
- * (test.c:39-42,98-101); the device cannot call back, so the stream goes to a host
- * buffer (memory mode, bitstream.h:34-43) -- see INTEGRATION.md for the replay loop.
+ * File mode: like the reference, every case is compressed INTO A FILE ("~compressed~.bin",
+ * test.c:163) and verified FROM that file, and the file holds what the reference's harness
+ * writes: the 64-bit words of the stream in host byte order (fwrite(&b64, 8, 1), test.c:39-42,
+ * read back with fread, test.c:98-101).  The device cannot call back per word, so the stream
+ * is produced in a host buffer (memory mode, bitstream.h:34-43) and sqz_file_words() turns it
+ * into the file image (the .file images under tests/golden are the reference's own files).
+ * locate_test_folder() (test.c:183-193) walks up until the corpus is found.
+ * SQZ_HARNESS_KEEP=<dir> additionally keeps each named case as <dir>/<name>.w<bits>.file.
  *
  * Build:  gcc -std=c99 -O2 -Iinclude tests/harness/sqz_harness.c -Lsqz_amd/lib -lsqz_amd
  *         -Wl,-rpath,$PWD/sqz_amd/lib -o tests/harness/sqz_harness
  * Run:    tests/harness/sqz_harness [win_bits] [corpus_dir]     (needs an MI355X)
  */
+#define _POSIX_C_SOURCE 200809L   /* getcwd, chdir */
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <sqz/sqz.h>
 
@@ -40,12 +47,24 @@ static int read_fully(const char* fn, uint8_t** data, size_t* bytes) {
     return *bytes == (size_t)n ? 0 : EIO;
 }
 
-/* test.c:44-96 compress + test.c:103-162 verify, in memory */
-static int test(const char* name, const uint8_t* data, size_t bytes) {
+static const char* compressed = "~compressed~.bin";                    /* test.c:163 */
+
+static int write_image(const char* to, const uint8_t* image, uint64_t bytes) {
+    FILE* out = fopen(to, "wb");                                       /* test.c:47 */
+    if (out == NULL) { printf("Failed to create \"%s\": %s\n", to, strerror(errno)); return errno; }
+    int r = fwrite(image, 1, (size_t)bytes, out) == (size_t)bytes ? 0 : (errno != 0 ? errno : EIO);
+    if (fclose(out) != 0 && r == 0) {                                  /* test.c:72-76 */
+        r = errno;
+        printf("Failed to flush on file close: %s\n", strerror(r));
+    }
+    return r;
+}
+
+/* test.c:44-96: header + payload through the vtable, then the file the reference writes */
+static int compress(const char* from, const char* to, const uint8_t* data, size_t bytes) {
     const uint64_t capacity = sqz_bound(bytes) + 16;
     uint8_t* comp = (uint8_t*)malloc(capacity);
-    uint8_t* back = (uint8_t*)malloc(bytes + 1);
-    if (comp == NULL || back == NULL) { free(comp); free(back); return ENOMEM; }
+    if (comp == NULL) { return ENOMEM; }
     int r = 0;
     bitstream bs = { .data = comp, .capacity = capacity };
     squeeze.write_header(&bs, bytes, (uint8_t)bits_win);               /* test.c:54 */
@@ -53,7 +72,7 @@ static int test(const char* name, const uint8_t* data, size_t bytes) {
     squeeze_type* s = NULL;
     if (r == 0) {
         s = squeeze.alloc(0);                                          /* test.c:59 */
-        if (s == NULL) { r = ENOMEM; }
+        if (s == NULL) { r = ENOMEM; printf("squeeze_new() failed.\n"); }
     }
     if (r == 0) {
         squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << bits_win));   /* test.c:61 */
@@ -63,37 +82,87 @@ static int test(const char* name, const uint8_t* data, size_t bytes) {
     if (r != 0) {
         printf("Failed to compress: %s\n", strerror(r));
     } else {
+        r = sqz_file_words(comp, bs.bytes, comp);                      /* words in host order, in place */
+        if (r == 0) { r = write_image(to, comp, bs.bytes); }
+        const char* keep = getenv("SQZ_HARNESS_KEEP");
+        if (r == 0 && keep != NULL && from != NULL) {
+            const char* fn = strrchr(from, '/');                       /* basename, test.c:81-83 */
+            fn = fn != NULL ? fn + 1 : from;
+            char path[1024];
+            snprintf(path, sizeof(path), "%s/%s.w%d.file", keep, fn, bits_win);
+            r = write_image(path, comp, bs.bytes);
+        }
+    }
+    if (r == 0) {
+        const char* fn = from == NULL ? NULL : strrchr(from, '/');
+        fn = fn != NULL ? fn + 1 : from;
         const double percent = bytes > 0 ? bs.bytes * 100.0 / (double)bytes : 0.0;
-        if (name != NULL) {                                            /* test.c:85-88 */
-            printf("%7lld -> %7lld %5.1f%% of \"%s\"\n", (long long)bytes, (long long)bs.bytes, percent, name);
+        if (from != NULL) {                                            /* test.c:85-88 */
+            printf("%7lld -> %7lld %5.1f%% of \"%s\"\n", (long long)bytes, (long long)bs.bytes, percent, fn);
         } else {
             printf("%7lld -> %7lld %5.1f%%\n", (long long)bytes, (long long)bs.bytes, percent);
         }
-        bitstream rd = { .data = comp, .bytes = bs.bytes };            /* test.c:110 */
-        uint64_t n = 0; uint8_t win_bits = 0;
-        squeeze.read_header(&rd, &n, &win_bits);                       /* test.c:114 */
-        if (rd.error != 0 || n != bytes || win_bits != bits_win) {
-            printf("Failed to read header\n");
-            r = rd.error != 0 ? rd.error : EINVAL;
-        } else {
-            s = squeeze.alloc(0);                                      /* test.c:121 */
-            if (s == NULL) { r = ENOMEM; }
-            else {
-                squeeze.decompress(s, &rd, back, (size_t)n);           /* test.c:134 */
-                r = s->error;
-                squeeze.free(s);
-            }
-            if (r == 0 && memcmp(data, back, bytes) != 0) {            /* test.c:138-144 */
-                size_t k = 0;
-                while (k < bytes && data[k] == back[k]) { k++; }
-                printf("Decompressed data does not match input at offset %lld\n", (long long)k);
-                r = EINVAL;
-            }
-        }
     }
     free(comp);
-    free(back);
     return r;
+}
+
+/* test.c:103-162: read the file back, decompress, compare */
+static int verify(const char* fn, const uint8_t* input, size_t size) {
+    uint8_t* image = NULL; size_t n_image = 0;
+    int r = read_fully(fn, &image, &n_image);
+    if (r != 0) { printf("Failed to open \"%s\"\n", fn); return r; }
+    uint8_t* back = (uint8_t*)malloc(size + 1);
+    if (back == NULL) { free(image); return ENOMEM; }
+    r = sqz_file_words(image, n_image, image);                         /* file words -> stream */
+    bitstream rd = { .data = image, .bytes = n_image };                /* test.c:110 */
+    uint64_t n = 0; uint8_t win_bits = 0;
+    if (r == 0) {
+        squeeze.read_header(&rd, &n, &win_bits);                       /* test.c:114 */
+        if (rd.error != 0 || n != size || win_bits != bits_win) {
+            printf("Failed to read header\n");
+            r = rd.error != 0 ? rd.error : EINVAL;
+        }
+    }
+    if (r == 0) {
+        squeeze_type* s = squeeze.alloc(0);                            /* test.c:121 */
+        if (s == NULL) { r = ENOMEM; }
+        else {
+            squeeze.decompress(s, &rd, back, (size_t)n);               /* test.c:134 */
+            r = s->error;
+            squeeze.free(s);
+        }
+        if (r == 0 && memcmp(input, back, size) != 0) {                /* test.c:138-144 */
+            size_t k = 0;
+            while (k < size && input[k] == back[k]) { k++; }
+            printf("Decompressed data does not match input at offset %lld\n", (long long)k);
+            r = EINVAL;
+        }
+    }
+    free(back);
+    free(image);
+    return r;
+}
+
+static int test(const char* fn, const uint8_t* data, size_t bytes) {   /* test.c:165-172 */
+    int r = compress(fn, compressed, data, bytes);
+    if (r == 0) { r = verify(compressed, data, bytes); }
+    (void)remove(compressed);
+    return r;
+}
+
+/* test.c:183-193: walk up until the test files are found (the snapshot's corpus lives in
+ * tests/corpus; the reference looks for test/bible.txt) */
+static int locate_test_folder(char* dir, size_t cap) {
+    for (int up = 0; up < 16; up++) {
+        FILE* f = fopen("tests/corpus/laozi.txt", "rb");
+        if (f != NULL) {
+            fclose(f);
+            return getcwd(dir, cap) != NULL ? 0 : errno;
+        }
+        if (chdir("..") != 0) { return errno; }
+    }
+    return ENOENT;
 }
 
 static int test_file(const char* dir, const char* fn) {
@@ -109,7 +178,12 @@ static int test_file(const char* dir, const char* fn) {
 
 int main(int argc, const char* argv[]) {
     if (argc > 1) { bits_win = atoi(argv[1]); }
+    static char root[1024];
     const char* corpus = argc > 2 ? argv[2] : "tests/corpus";
+    if (argc <= 2) {                                                   /* test.c:197 */
+        const int lr = locate_test_folder(root, sizeof(root));
+        if (lr != 0) { printf("test files not found: %s\n", strerror(lr)); return lr; }
+    }
     char name[128]; int cus = 0; uint64_t lds = 0;
     int r = sqz_hip_device_info(name, sizeof(name), &cus, &lds);
     if (r != 0) { printf("no gfx950 device: %s\n", strerror(r)); return r; }

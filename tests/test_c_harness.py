@@ -51,3 +51,15 @@ def test_harness_passes_reference_cases(harness, win_bits):
                 assert int(ln.split("->")[1].split()[0]) == size, ln
                 seen += 1
     assert seen == len(want)
+
+
+@pytest.mark.gpu
+def test_harness_writes_the_reference_file_image(harness, tmp_path):
+    """file mode (attic test.c:39-42): the kept file equals the one the compiled reference wrote"""
+    env = dict(os.environ, SQZ_HARNESS_KEEP=str(tmp_path))
+    p = subprocess.run([harness, "10"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    kept = tmp_path / "laozi.txt.w10.file"
+    with open(os.path.join(ROOT, "tests", "golden", "laozi.txt.w10.file"), "rb") as fh:
+        assert kept.read_bytes() == fh.read()
+    assert not os.path.exists(os.path.join(ROOT, "~compressed~.bin"))      # removed like test.c:170
