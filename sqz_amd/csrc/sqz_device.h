@@ -479,8 +479,13 @@ struct Tree {
     }
 
     // huffman.h:149-216
-    __device__ __forceinline__ bool insert(int i) {
-        bool ok = true;
+    // huffman.h:149-209, one lane: hang leaf i into the tree.  Leaves every field of the
+    // nodes it touches valid (depth, up2, up3 as well), so that the whole-wave climb can start
+    // from the result.  Returns  start | at << 10 | ok << 20 : the node huffman_frequency_changed
+    // is called on (:212; the OTHER sibling when the pair was reordered, :173) and the node
+    // whose subtree is relabelled afterwards (:213).
+    __device__ __forceinline__ uint32_t insert_splice(int i) {
+        uint32_t ok = 1;
         int at = kRoot;
         freq[i] = 1;
         while (at >= LEAVES) {                                        // :156-170
@@ -489,7 +494,8 @@ struct Tree {
                 if (n.hi == kNil) { n.hi = (uint32_t)i; } else { n.lo = (uint32_t)i; }
                 st(at, n);
                 Node ni = ld(i);
-                ni.up = (uint32_t)at;
+                ni.up = (uint32_t)at; ni.up2 = n.up; ni.up3 = n.up2;
+                ni.bits = n.bits + 1;
                 st(i, ni);
                 break;
             }
@@ -499,7 +505,7 @@ struct Tree {
             freq[at] += 1;
             i = order_pair(i);
         } else if (next >= kIdEnd) {                                  // :180-182
-            ok = false;
+            ok = 0;
             complete = 1;
         } else {                                                      // :184-209
             const int fresh = next++;
@@ -514,19 +520,24 @@ struct Tree {
                 else                            { nabove.hi = (uint32_t)fresh; }
                 st((int)na.up, nabove);
             }
-            na.up = (uint32_t)fresh;
-            na.bits = na.bits + 1;
+            na.up = (uint32_t)fresh; na.up2 = nf.up; na.up3 = nf.up2;
+            na.bits = nf.bits + 1;
             st(at, na);
             Node ni = ld(i);
-            ni.up = (uint32_t)fresh;
+            ni.up = (uint32_t)fresh; ni.up2 = nf.up; ni.up3 = nf.up2;
             ni.bits = nf.bits + 1;
             st(i, ni);
             sum(fresh);
             at = fresh;
         }
-        changed(i);                                                   // :212
-        relabel(at);                                                  // :213
-        return ok;
+        return (uint32_t)i | ((uint32_t)at << 10) | (ok << 20);
+    }
+
+    __device__ __forceinline__ bool insert(int i) {                   // everything on one lane
+        const uint32_t h = insert_splice(i);
+        changed((int)(h & 0x3FFu));                                   // :212
+        relabel((int)((h >> 10) & 0x3FFu));                           // :213
+        return (h >> 20) != 0;
     }
 
     // whole wave: insert through lane 0 (unseen symbols are rare: <= 286 per stream)
@@ -776,9 +787,20 @@ __device__ __noinline__ uint32_t slow_insert(uint64_t* link, uint32_t* freq, Tre
     T t;
     t.link = link; t.freq = freq; t.scratch = scratch; t.lut = nullptr; t.lut_ok = 0;
     t.unpack_regs(regs);
-    int ok = 1;
-    if (lane == 0) { ok = t.insert(sym) ? 1 : 0; }
-    const uint32_t r = t.pack_regs() | ((uint32_t)ok << 31);
+    // the splice on lane 0, the climb and the promotions on the whole wave (as for any other
+    // restructure), the closing relabel of the small subtree the leaf went into on lane 0
+    uint32_t hand = 0;
+    if (lane == 0) { hand = t.insert_splice(sym); }
+    t.unpack_regs((uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs()));
+    hand = (uint32_t)__builtin_amdgcn_readfirstlane((int)hand);
+    const int start = (int)(hand & 0x3FFu), at = (int)((hand >> 10) & 0x3FFu);
+    if (t.depth + 4 >= kMaxFastDepth) {                 // chains too long for one lane per level
+        if (lane == 0) { t.changed(start); }
+    } else {
+        t.changed_all(start, lane);
+    }
+    if (lane == 0) { t.relabel(at); }
+    const uint32_t r = t.pack_regs() | ((hand >> 20) << 31);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
 
