@@ -284,6 +284,10 @@ __device__ __forceinline__ int lane_below(int v) {          // lane k <- lane k-
     return __builtin_amdgcn_update_dpp((int)kNil, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+__device__ __forceinline__ uint32_t lanes_under(uint64_t mask) {      // bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // inclusive prefix sum over the wavefront in six DPP steps (row scans, then the row totals)
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
@@ -663,6 +667,55 @@ struct Tree {
         fault = (__ballot(fault != 0) != 0) ? 1 : 0;
     }
 
+    // After a promotion only the two subtrees that traded places changed depth / up2 / up3.
+    // Fix them top-down, one tree level per pass, one lane per node of the level (their
+    // children queue up for the next pass).  A level wider than the wave, or a promotion
+    // under the root (the reference's walk from the root restarts the depth mark), goes
+    // through the fixpoint over all nodes instead.
+    __device__ __forceinline__ void relabel_moved(int a, int b, bool reset, int lane) {
+        if (reset) { relabel_wave(true, lane); return; }
+        uint16_t* const q = scratch->walk;                     // two queues of 64
+        if (lane == 0) { q[0] = (uint16_t)a; q[1] = (uint16_t)b; }
+        int n = 2, cur = 0;
+        uint32_t seen = 0;
+        bool wide = false;
+        for (int level = 0; n > 0; level++) {
+            if (level >= 70) { wide = true; break; }               // never: deeper than any tree
+            const bool on = lane < n;
+            const int v = on ? (int)q[cur + lane] : kRoot;
+            const uint64_t w = link[v];
+            const uint32_t up = on ? ((uint32_t)w & 0x3FFu) : (uint32_t)kRoot;
+            const uint64_t pw = link[up];
+            uint32_t d = (((uint32_t)(pw >> 32) >> 20) & 0x3Fu) + 1u;
+            if (on && (d > 63u || (d == 63u && v >= LEAVES))) { fault = 1; }
+            d = d > 63u ? 63u : d;
+            const uint32_t kids = (uint32_t)(w >> 32) & 0xFFFFFu;
+            if (on) {
+                link[v] = (uint64_t)(up | (((uint32_t)pw & 0xFFFFFu) << 10)) | ((uint64_t)(kids | (d << 20)) << 32);
+                seen = d > seen ? d : seen;
+            }
+            const uint32_t lo = kids & 0x3FFu, hi = (kids >> 10) & 0x3FFu;
+            const bool has_lo = on && lo != kNil, has_hi = on && hi != kNil;
+            const uint64_t mlo = __ballot(has_lo), mhi = __ballot(has_hi);
+            const int nlo = __builtin_popcountll(mlo), nhi = __builtin_popcountll(mhi);
+            if (nlo + nhi > kWave) { wide = true; break; }
+            const int nxt = cur ^ kWave;
+            if (has_lo) { q[nxt + (int)lanes_under(mlo)] = (uint16_t)lo; }
+            if (has_hi) { q[nxt + nlo + (int)lanes_under(mhi)] = (uint16_t)hi; }
+            n = nlo + nhi;
+            cur = nxt;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)seen, o);
+            seen = other > seen ? other : seen;
+        }
+        const int top = __builtin_amdgcn_readfirstlane((int)seen);
+        if (top > depth) { depth = top; }
+        fault = (__ballot(fault != 0) != 0) ? 1 : 0;
+        if (wide) { relabel_wave(false, lane); }
+    }
+
     // the climb of huffman_frequency_changed from node i (huffman.h:132-142): lane k
     // owns level k of i's root path; new sums by prefix sum, sibling order per level,
     // one pending pair per level (bottom first)
@@ -745,7 +798,7 @@ struct Tree {
                 order_only(uncle);
                 order_only(p);
             }
-            relabel_wave(g == kRoot, lane);
+            relabel_moved(ch, uncle, g == kRoot, lane);
             sp = climb_wave(g, sp, lane);                             // :126
         }
     }
