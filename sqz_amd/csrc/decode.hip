@@ -345,6 +345,9 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         // ---- whatever stopped the step: one token, exactly ------------------------------------
 #ifdef SQZ_STATS
         st_steps++; st_m += (uint32_t)m; st_done += (uint32_t)done;
+#ifdef SQZ_STATS_SERIES
+        if (lane == 0 && b == 1) { printf("S %d %d %d %d\n", want, m, done, (int)stop); }
+#endif
         st_hist[done == 0 ? 0 : done < 8 ? 1 : done < 24 ? 2 : done < 64 ? 3 : 4]++;
 #endif
         ST_SEC(4)
@@ -352,7 +355,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         ST_SEC(5)
         {   // a step that ran short is usually followed by more short ones (the tree is still moving)
             avg4 += done - (avg4 >> 2);
-            want = (avg4 >> 1) + 6;                           // twice the recent mean, and a little
+            want = ((avg4 * 3) >> 3) + 6;                     // 1.5 x the recent mean, and a little (offline
+                                                              // what-if over a recorded step series: tools/readahead_policy.py)
             want = want < kWave ? want : kWave;
         }
     }

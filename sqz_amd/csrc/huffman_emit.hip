@@ -232,6 +232,13 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
     uint32_t* const freq = lds.entropy.lit_freq;
     uint32_t cursor = 0, sbase = 0, shave = 0;        // strip holds tokens [sbase, sbase+shave)
+#ifdef SQZ_STATS
+    uint64_t es[4] = {0, 0, 0, 0}, es_last = __builtin_readcyclecounter(), es_begin = es_last;
+    uint32_t es_steps = 0, es_exact = 0;
+#define ES(k) { const uint64_t n_ = __builtin_readcyclecounter(); es[k] += n_ - es_last; es_last = n_; }
+#else
+#define ES(k)
+#endif
     while (cursor < count && err == 0) {
         if (cursor + kWave > sbase + shave && sbase + shave < count) {   // restage from the cursor
             sbase = cursor;
@@ -264,8 +271,10 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         uint64_t ca = 0, cb = 0;
         int wa = 0, wb = 0;
         const int offered = m;
+        ES(0)
         if (m >= 1 && !frozen) { m = bump_lanes(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
         else { m = 0; }
+        ES(1)
         if (m >= 1) {
             // this lane's bits: code [extra] [code extra], first-out bit on top
             uint64_t v = ca;
@@ -282,6 +291,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             q.pack_lanes(v, n, lane);
             cursor += (uint32_t)m;
         }
+        ES(2)
         if (m < offered || offered == 0 || frozen) {
             // the token the step stopped at (NYT escape / the tree restructures / frozen tree):
             // one symbol at a time, always exact
@@ -289,11 +299,26 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             emit_token(q, lit, pos, tx, lane, err);
             if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
             cursor += 1;
+#ifdef SQZ_STATS
+            es_exact++;
+#endif
         }
+        ES(3)
+#ifdef SQZ_STATS
+        es_steps++;
+#endif
         if (q.error != 0) { err = q.error; }
         if (lit.fault | pos.fault) { err = kE2BIG; }
     }
 
+#ifdef SQZ_STATS
+    if (lane == 0 && b == 1) {
+        printf("emit block 1: cycles %llu steps %u exact %u: prep %llu bump %llu pack %llu exact %llu\n",
+               (unsigned long long)(es_last - es_begin), es_steps, es_exact, (unsigned long long)es[0],
+               (unsigned long long)es[1], (unsigned long long)es[2], (unsigned long long)es[3]);
+        printf("emit bump: open %llu count %llu mid %llu add %llu count-iters %llu\n", g_st[0], g_st[1], g_st[2], g_st[3], g_st[4]);
+    }
+#endif
     if (err == 0) { q.flush(lane); err = q.error; }
     else { q.pack(lane); }
     if (lane == 0) {

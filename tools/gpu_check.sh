@@ -15,5 +15,5 @@ for l in open("gpurun_out/b.log"):
         print(d["value"], d["unit"], "decode", d.get("decode_MBps"), d.get("kernels_ms"), d.get("roofline"))
 PY
 if [ -f sqz_amd/lib/libsqz_amd_stats.so ]; then
-  SQZ_AMD_LIB=$PWD/sqz_amd/lib/libsqz_amd_stats.so timeout -k 10 200 python bench.py --steps 1 --warmup 0 --cpu-blocks 0 2>&1 | grep -E "^block|^cycles|^lit|^bump|^wall" | cut -c1-300
+  SQZ_AMD_LIB=$PWD/sqz_amd/lib/libsqz_amd_stats.so timeout -k 10 200 python bench.py --steps 1 --warmup 0 --cpu-blocks 0 2>&1 | grep -E "^block|^cycles|^lit|^bump|^wall|^emit" | cut -c1-300
 fi
