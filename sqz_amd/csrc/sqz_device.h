@@ -11,7 +11,7 @@
 //   huffman.h:149-216 huffman_insert       -> Tree::insert
 //   huffman.h:218-235 huffman_inc_frequency-> Tree::bump
 //   squeeze.h:29-79,151-172 DEFLATE tables -> len_code()/pos_code() arithmetic
-//   bitstream.h:28-63,112-114 bit packer   -> BitSink
+//   bitstream.h:28-63,112-114 bit packer   -> BitQueue (huffman_emit.hip)
 //   bitstream.h:65-103 bit reader          -> BitSource
 //
 // Layout decisions:
@@ -81,64 +81,6 @@ __device__ __forceinline__ void pos_base_of(int code, int& base, int& xbits) {
     if (code < 4) { base = code + 1; xbits = 0; }
     else { xbits = (code >> 1) - 1; base = ((2 + (code & 1)) << xbits) + 1; }
 }
-
-// ---------------------------------------------------------------------------
-// Bit sink: values go out LSB first, bits fill a 64-bit word from the top,
-// words are stored big-endian (bitstream.h:30-43,55-63).
-// The sink is driven wave-uniformly (every lane holds the same state, so the
-// state lives in SGPRs); only lane 0 touches memory.
-struct BitSink {
-    uint8_t* out;       // global
-    uint64_t capacity;
-    uint64_t bytes;
-    uint64_t acc;
-    int      fill;
-    int      error;
-    bool     writer;    // lane 0
-
-    __device__ __forceinline__ void word() {
-        if (error != 0) { return; }
-        if (capacity - bytes >= 8) {
-            if (writer) { *reinterpret_cast<uint64_t*>(out + bytes) = __builtin_bswap64(acc); }
-            bytes += 8;
-        } else {                       // bitstream.h:36-43: byte by byte
-            for (int k = 0; k < 8 && error == 0; k++) {
-                if (bytes == capacity) { error = kE2BIG; }
-                else {
-                    if (writer) { out[bytes] = (uint8_t)(acc >> (56 - 8 * k)); }
-                    bytes++;
-                }
-            }
-        }
-        acc = 0;
-        fill = 0;
-    }
-
-    // append `nbits` (1..63) whose first-out bit is the MOST significant one
-    __device__ __forceinline__ void put_msb(uint64_t v, int nbits) {
-        if (error != 0) { return; }
-        const int room = 64 - fill;
-        if (nbits < room) {
-            acc = (acc << nbits) | v;
-            fill += nbits;
-        } else {
-            const int rest = nbits - room;             // 0..62
-            acc = (fill == 0 ? 0 : (acc << room)) | (v >> rest);
-            word();
-            acc = v & ((1ULL << rest) - 1);
-            fill = rest;
-        }
-    }
-
-    // value LSB first (squeeze_write_bits, squeeze.h:231-237), nbits 1..32
-    __device__ __forceinline__ void put_lsb(uint32_t v, int nbits) {
-        put_msb((uint64_t)(__brev(v) >> (32 - nbits)), nbits);
-    }
-
-    __device__ __forceinline__ void flush() {          // bitstream.h:112-114
-        if (fill > 0 && error == 0) { acc <<= (64 - fill); word(); }
-    }
-};
 
 // Bit source over global memory (bitstream.h:65-93): the stream is read MSB
 // first; the reference fetches it in 8-byte big-endian groups and fails with
@@ -304,9 +246,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
-// one lane's share of a root path: its node, that node's parent and grandparent
+// one lane's share of a root path: its node and that node's parent
 struct Chain {
-    int mine, par, gpar;
+    int mine, par;
     int levels;        // uniform: edges between leaf and root
     bool holds;        // this lane holds a node of the path
     bool active;       // ... and the node has a parent
@@ -603,7 +545,6 @@ struct Tree {
         Chain c;
         c.mine = mine;                       // lanes beyond `levels` hold nil (or junk: not `holds`)
         c.par = lane_above(mine);            // lane k+1 holds the parent
-        c.gpar = lane_above(c.par);
         c.levels = levels;
         c.holds = lane <= levels;
         c.active = lane < levels;
@@ -943,9 +884,9 @@ struct EntropyLds {
 };
 
 // ---------------------------------------------------------------------------
-// Four symbols per step.  Both trees are one array pair (pos ids + kLitNodes),
-// quarter q of the wave (one DPP row = 16 lanes) owns symbol q, its lane l owns
-// level l of that symbol's leaf->root chain.
+// Up to 64 tokens per step: lane = token (its lit-tree symbol, then, for a back
+// reference, its pos-tree symbol); every lane walks its own leaf->root chains.  Both trees
+// are one array pair (pos ids + kLitNodes).
 //
 // Exactness: the reference updates the symbols one after another.  It would
 // change no link during the whole step if, for every chain node c (parent p,
@@ -956,87 +897,14 @@ struct EntropyLds {
 // (induction over the sequential updates: every count only grows, c's count
 // never exceeds f0(c)+n(c), s and u never drop below f0; a lo sibling that is
 // itself on a chain is covered by its own first test).  Then the result of the
-// step is f0 + n on every chain node and every code is the static tree's, which is
-// what the lanes produce with LDS atomic adds.  If any test fails, the adds are
-// undone and the caller feeds the symbols to the one-at-a-time path, so the tests
-// may be conservative but the output is always the reference's.
-constexpr int kBatch = 4;
-constexpr int kBatchDepth = 15;
-constexpr int kUnifiedDummy = kLitLeaves;        // the lit root: always a valid slot
-
-__device__ __forceinline__ int row_above(int v, int fill) {          // lane l <- lane l+1, same row
-    return __builtin_amdgcn_update_dpp(fill, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-}
-
-struct BatchOut {
-    uint64_t code_bits;      // quarter q's code = bits 16q .. 16q+depth-1 (stream order)
-    uint32_t depths;         // depth of symbol q in byte q
-};
-
-__device__ __forceinline__ bool bump_batch(uint64_t* link, uint32_t* freq,
-                                           int s0, int s1, int s2, int s3, int n, int lane,
-                                           BatchOut& out) {
-    const int q = lane >> 4, l = lane & 15;
-    const bool live = q < n;
-    int leaf = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));     // unified id
-    leaf = live ? leaf : kUnifiedDummy;
-    const int base = leaf >= kLitNodes ? kLitNodes : 0;
-    const uint64_t w0 = link[leaf];
-    const int depth = (int)((uint32_t)(w0 >> 52) & 0x3Fu);
-    const bool bad = live & (depth == 0 || depth > kBatchDepth);     // unseen / too deep
-    uint32_t w = (uint32_t)w0;
-    int mine = (l == 0) ? (leaf - base) : (int)kNil;                   // ids local to the tree
-    int k = 0;
-#pragma unroll 1
-    for (int it = 0; it < 5; it++) {
-        const uint32_t f = (uint32_t)(l - k - 1);
-        const uint32_t pick = (w >> (f < 3u ? 10u * f : 0u)) & 0x3FFu;
-        mine = (f < 3u) ? (int)pick : mine;
-        k += 3;
-        const bool more = live & !bad & (k < depth);
-        if (__ballot(more) == 0) { break; }
-        const int a = (int)((w >> 20) & 0x3FFu);
-        if (more) { w = reinterpret_cast<const uint32_t*>(link)[2 * (base + a)]; }
-    }
-    const bool holds = live & !bad & (l <= depth);
-    const bool active = live & !bad & (l < depth);
-    const bool has_g = live & !bad & (l + 1 < depth);
-    const int par = row_above(mine, (int)kNil);
-    const int i_mine = holds ? base + mine : kUnifiedDummy;
-    const int i_par = active ? base + par : kUnifiedDummy;
-    const uint32_t fc = freq[i_mine];
-    const Node lp = unpack(link[i_par]);
-    const bool is_hi = active & (lp.hi == (uint32_t)mine);
-    const uint32_t sib = is_hi ? lp.lo : lp.hi;
-    const bool has_sib = active & (sib != kNil);
-    const uint32_t fs = freq[has_sib ? base + (int)sib : kUnifiedDummy];
-    const uint32_t fu = (uint32_t)row_above((int)fs, 0);
-    const bool has_unc = is_hi & has_g & (row_above(has_sib ? 1 : 0, 0) == 1);
-    // all reads above see the counts before the step; now add
-    if (holds) { atomicAdd(&freq[i_mine], 1u); }
-    const uint32_t ff = freq[i_mine];                                   // f0 + n
-    const bool flag = bad | (has_sib & (is_hi ? (fs > fc + 1) : (ff > fs))) | (has_unc & (ff > fu));
-    if (__ballot(flag) != 0) {
-        if (holds) { atomicSub(&freq[i_mine], 1u); }
-        return false;
-    }
-    out.code_bits = __ballot(is_hi);
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(depth, 0);
-    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane(depth, 16);
-    const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane(depth, 32);
-    const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane(depth, 48);
-    out.depths = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
-    return true;
-}
-
-// ---------------------------------------------------------------------------
-// Up to 64 tokens per step: lane = token (its lit-tree symbol, then, for a back
-// reference, its pos-tree symbol); every lane walks its own leaf->root chains.
-// Same exactness argument as bump_batch above.  n(c) is counted in the top 7 bits
-// of the count word with LDS atomic adds whose return value tells a lane how many
-// lanes were counted at c before it (its rank r).  A lane is `bad` if, at some node
-// of its chains, f0(c) + r + 1 would break one of the three tests.  Take the
-// tokens in front of the first bad lane: for every node at most `allowed` of them
+// step is f0 + n on every chain node and every code is the static tree's.  The tests
+// may be conservative -- the token a step stops at goes through the one-at-a-time
+// path -- but the output is always the reference's.
+//
+// n(c) is counted in the top 7 bits of the count word with LDS atomic adds whose return
+// value tells a lane how many lanes were counted at c before it (its rank r).  A lane is
+// `bad` if, at some node of its chains, f0(c) + r + 1 would break one of the three tests.
+// Take the tokens in front of the first bad lane: for every node at most `allowed` of them
 // pass through it (they all have rank < allowed), so the tests hold for that prefix
 // whatever order the hardware serialises same-address atomics in -- a different
 // order can only shorten the prefix.  Two sweeps over the chains:

@@ -328,3 +328,37 @@ def test_corrupt_streams_do_not_fault(sq, batch):
         assert ge == e
         if e == 0:
             assert got == out
+
+
+def test_one_large_stream(sq, batch):
+    """One 24 MB stream: more than 2^24 bytes (the index sort stops carrying the key byte in
+    the element, lz77_index.hip) and more than 2^24 tokens (the entropy kernels stop batching
+    and take every token through the exact path, huffman_emit.hip / decode.hip).  The oracle
+    is O(n * window) and out of reach at this size, so parity rests on the differential
+    pattern of bst.c:254-308 -- the indexed finder must give the brute-force scan's tokens,
+    all of them -- on the oracle for the first tokens, and on the round trip."""
+    import torch
+    n_bytes, window = 24 * (1 << 20), 1 << 10
+    d_in = batch.zipf_blocks(1, n_bytes, first_block=11)
+    off = batch.uniform_offsets(1, n_bytes)
+    enc = batch.Encoder(1, n_bytes, sq.bound(n_bytes))
+    t_index, c_index = enc.tokens(d_in, off, window, finder="index")
+    t_scan, c_scan = enc.tokens(d_in, off, window, finder="scan")
+    torch.cuda.synchronize()
+    n_tok = int(c_scan[0])
+    assert n_bytes > (1 << 24) and n_tok > (1 << 24)
+    assert int(c_index[0]) == n_tok
+    assert bool((t_index[:n_tok] == t_scan[:n_tok]).all())
+    # the first tokens depend only on the bytes in front of them: the oracle pins them
+    head = bytes(d_in[:40000].cpu().numpy())
+    want = O.tokens(head, window)[:3000]
+    assert (t_index[:len(want)].cpu().numpy().view(np.uint32) == want).all()
+    # entropy stages past the batching limit, and back
+    out, out_off, out_bytes, err = enc.encode(d_in, off, window)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0 and 0 < int(out_bytes[0]) < n_bytes
+    back = torch.empty_like(d_in)
+    derr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    batch.decode_blocks(out, out_off, 1, back, off, derr)
+    torch.cuda.synchronize()
+    assert int(derr[0]) == 0 and bool((back == d_in).all())
