@@ -5,15 +5,17 @@
 //       squeeze.h:429-442 squeeze_read_huffman root->leaf walk, then frequency bump
 //       squeeze.h:458-474 squeeze_read_length
 //       squeeze.h:476-500 squeeze_read_pos
-//     The root->leaf walk hands level d of the path to lane d, so the frequency
-//     update right after it is the parallel fast path of sqz_device.h (the walk
-//     has already produced the chain the update needs).  Output: the same token
-//     words stage 1 of the encoder produces (literal / len<<16|dist).
-//   lz_expand_kernel        one wavefront per stream: squeeze.h:521-539.  The
-//     output window lives in LDS (like the encoder's scan), 64 tokens per step:
-//     literals land in parallel, back references are copied by all 64 lanes
-//     with the byte-serial overlap rule out[i+k] = out[i-dist + (k mod dist)]
-//     (RLE when dist < len), finished bytes leave for HBM in 16-byte rows.
+//     With the trees held still, lane l decodes the token that would start at bit l of a
+//     staged piece of the stream; the real starts are picked by following the lengths, and
+//     up to 64 tokens then update the trees at once (sqz_device.h: bump_lanes).  The token
+//     a step stops at (a restructure, an unseen symbol) takes the one-at-a-time path, where
+//     the root->leaf walk hands level d of the path to lane d.  Output: the same token words
+//     stage 1 of the encoder produces (literal / len<<16|dist).
+//   lz_expand_kernel        one wavefront per stream: squeeze.h:521-539, 64 tokens per step.
+//     The window is the output buffer itself, read back through the L2: literals land in
+//     parallel, short back references are copied by their own lanes side by side, the rest by
+//     all 64 lanes with the byte-serial overlap rule out[i+k] = out[i-dist + (k mod dist)]
+//     (RLE when dist < len).
 //
 // Hardening (the reference only asserts): a missing
 // child, a raw symbol that is out of range or already in the tree, a distance
@@ -385,107 +387,89 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------
-constexpr int kExpRegion = 39936;            // resident output bytes (x16): 32767 back + room
-constexpr int kExpSlack  = 1024;
+// LZ77 expansion (squeeze.h:521-539) with the window where it already is: the output buffer,
+// served by the L2.  A window staged in LDS needs 40 KB per stream -- one wave per SIMD, four
+// rounds of workgroups for the batch, every latency exposed (22.4 ms); this needs no LDS, so
+// all streams are resident at once and four waves per SIMD hide each other's round trips
+// (6.8 ms).
+//
+// Bytes written by one lane are read by others, through memory: stores are write-through to
+// the L2, a workgroup-scope fence waits for them, and the source bytes of a back reference
+// are loaded with agent-scope (L2) loads, so nothing depends on what the L1 holds.
+// 64 tokens per step: literals all at once; back references whose source lies entirely in
+// front of the step (nearly all of them) by their own lanes, side by side; the rest -- the
+// source overlaps this step's output, or the copy is long -- one after the other with the
+// whole wave, in token order.
+constexpr int kExpOwnLane = 24;               // longest copy a single lane does by itself
 
-struct ExpandLds {
-    __attribute__((aligned(16))) uint8_t buf[kExpRegion + 16];
-};
+__device__ __forceinline__ uint8_t load_l2(const uint8_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(kWave)
 void lz_expand_kernel(const uint32_t* __restrict__ tokens,
-                      const uint32_t* __restrict__ tok_count,
-                      uint8_t* __restrict__ out,
-                      const uint64_t* __restrict__ out_off,
-                      uint32_t n_blocks) {
-    __shared__ ExpandLds lds;
-    uint8_t* const buf = lds.buf;
+                         const uint32_t* __restrict__ tok_count,
+                         uint8_t* __restrict__ out,
+                         const uint64_t* __restrict__ out_off,
+                         uint32_t n_blocks) {
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
-
     uint8_t* dst = out + out_off[b];
     const uint32_t* tok = tokens + out_off[b];
     const uint32_t count = tok_count[b];      // tokens decoded before an error are still expanded
-    const bool dst_aligned = ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
 
-    uint64_t base = 0;        // stream offset of buf[0] (multiple of 16)
-    uint64_t i = 0;           // next output byte
-    uint64_t flushed = 0;     // bytes [0, flushed) are in HBM (multiple of 16 until the end)
-
-    // buf[flushed-base, upto-base) -> dst[flushed, upto)
-    auto flush_to = [&](uint64_t upto) {
-        const uint64_t n = upto - flushed;
-        const uint8_t* p = buf + (flushed - base);
-        uint8_t* q = dst + flushed;
-        uint64_t done = 0;
-        if (dst_aligned && (flushed & 15u) == 0) {
-            const uint64_t rows = n / 16;
-            for (uint64_t k = lane; k < rows; k += kWave) {
-                *reinterpret_cast<uint4*>(q + k * 16) = *reinterpret_cast<const uint4*>(p + k * 16);
-            }
-            done = rows * 16;
-        }
-        for (uint64_t k = done + lane; k < n; k += kWave) { q[k] = p[k]; }
-        flushed = upto;
-    };
-
-    for (uint32_t t0 = 0; t0 < count; ) {
-        // ---- 64 tokens: lengths, prefix sum -> output offsets ------------------
+    uint64_t i = 0;                            // next output byte
+    uint32_t next_word = (uint32_t)lane < count ? tok[lane] : 0u;
+    for (uint32_t t0 = 0; t0 < count; t0 += kWave) {
         const uint32_t left = count - t0;
-        uint32_t word = 0, mylen = 0;
-        if ((uint32_t)lane < left) {
-            word = tok[t0 + lane];
-            mylen = (word & kTokMatch) ? ((word >> 16) & 0x1FFu) : 1u;
-        }
-        uint32_t incl = mylen;
-        incl = wave_scan(incl);
+        const bool mine_in = (uint32_t)lane < left;
+        const uint32_t word = next_word;
+        const uint32_t t1 = t0 + kWave + (uint32_t)lane;   // the next step's tokens are on their way
+        next_word = t1 < count ? tok[t1] : 0u;
+        const bool is_match = mine_in && (word & kTokMatch) != 0;
+        const uint32_t mylen = mine_in ? (is_match ? ((word >> 16) & 0x1FFu) : 1u) : 0u;
+        const uint32_t incl = wave_scan(mylen);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-        uint64_t room = (uint64_t)kExpRegion - (i - base);
-        if ((uint64_t)total > room && (i - base) > 32767 + kExpSlack) {
-            // make room: finished rows go to HBM, the last 32767 bytes stay
-            flush_to(i & ~(uint64_t)15);
-            const uint64_t new_base = (i - 32767) & ~(uint64_t)15;
-            const uint32_t shift = (uint32_t)(new_base - base);
-            const uint32_t live = (uint32_t)(i - new_base);
-            for (uint32_t off0 = 0; off0 < live; off0 += kWave * 16) {
-                const uint32_t off = off0 + (uint32_t)lane * 16;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (off < live) { v = *reinterpret_cast<const uint4*>(buf + shift + off); }
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_wave_barrier();
-                if (off < live) { *reinterpret_cast<uint4*>(buf + off) = v; }
+        const uint64_t o = i + (incl - mylen);             // where my token's bytes go
+        const uint32_t dist = word & 0x7FFFu;
+        // everything earlier steps wrote is in the L2 from here on
+        __threadfence_block();
+        if (mine_in && !is_match) { dst[o] = (uint8_t)word; }
+        // source entirely in front of this step, and short: my own lane copies it
+        const bool own = is_match && (o - dist) + mylen <= i && mylen <= (uint32_t)kExpOwnLane;
+        {   // four bytes per trip: the loads of a trip are independent of each other
+            const uint8_t* sp = dst + (own ? o - dist : 0);
+            uint8_t* dp = dst + (own ? o : 0);
+            const uint32_t n_own = own ? mylen : 0u;
+            for (uint32_t k0 = 0; __ballot(k0 < n_own) != 0; k0 += 4) {
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) { v[j] = k0 + j < n_own ? load_l2(sp + k0 + j) : (uint8_t)0; }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) { if (k0 + j < n_own) { dp[k0 + j] = v[j]; } }
             }
-            base = new_base;
-            room = (uint64_t)kExpRegion - (i - base);
         }
-        // the longest prefix of these tokens that fits (>= 1: room >= 257 here)
-        const uint64_t fits = __ballot((uint64_t)incl <= room && (uint32_t)lane < left);
-        const int ntake = __builtin_popcountll(fits);
-        const bool mine_in = lane < ntake;
-        const uint32_t o = (uint32_t)(i - base) + incl - mylen;  // LDS offset of my token's output
-        // ---- literals: all at once ------------------------------------------------
-        if (mine_in && (word & kTokMatch) == 0) { buf[o] = (uint8_t)word; }
-        // ---- back references: in token order, 64 lanes per copy --------------------
-        uint64_t mm = __ballot(mine_in && (word & kTokMatch) != 0);
+        uint64_t mm = __ballot(is_match && !own);
         while (mm != 0) {
+            __threadfence_block();                         // literals, own-lane copies, the copy before
             const int ml = __builtin_ctzll(mm);
             mm &= mm - 1;
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, ml);
-            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)o, ml);
+            const uint64_t at = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), ml) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, ml);
             const int len = (int)((w >> 16) & 0x1FFu);
-            const int dist = (int)(w & 0x7FFFu);
-            const uint8_t* srcp = buf + at - dist;
-            if (dist >= len) {
-                for (int k = lane; k < len; k += kWave) { buf[at + k] = srcp[k]; }
+            const int d = (int)(w & 0x7FFFu);
+            const uint8_t* sp = dst + (at - (uint64_t)d);
+            // out[at+k] = out[at-d+(k mod d)]: only bytes in front of `at` are read
+            if (d >= len) {
+                for (int k = lane; k < len; k += kWave) { dst[at + (uint64_t)k] = load_l2(sp + k); }
             } else {
-                for (int k = lane; k < len; k += kWave) { buf[at + k] = srcp[k % dist]; }
+                for (int k = lane; k < len; k += kWave) { dst[at + (uint64_t)k] = load_l2(sp + (k % d)); }
             }
         }
-        if (ntake > 0) { i += (uint32_t)__builtin_amdgcn_readlane((int)incl, ntake - 1); }
-        t0 += (uint32_t)ntake;
+        i += total;
     }
-    flush_to(i);
 }
 
 void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
