@@ -310,7 +310,7 @@ void index_match_kernel(const uint8_t* __restrict__ in,
 // where the previous chunk's path left -- only has to be followed until it steps on a
 // position the guess also visited; from there the guess is right.  That fix-up runs chunk
 // by chunk, a few hops each, instead of one hop per token.
-constexpr int kChunk = 64;                          // positions per lane
+constexpr int kChunk = 32;                          // positions per lane
 constexpr int kTile = kChunk * kWave;               // positions per pass
 constexpr int kChunkRow = kChunk + 1;               // padded: same-offset reads of all lanes spread over the banks
 
