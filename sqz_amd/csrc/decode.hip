@@ -188,7 +188,24 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
 #else
 #define ST_SEC(k)
 #endif
+    // All streams of the batch start together and the hardware serves the oldest wave of a
+    // SIMD first, so without help the first workgroups of a CU race ahead and the last ones
+    // finish alone, latency-bound, on a mostly idle CU.  A wave that is ahead steps back:
+    // priority 3 in its first quarter down to 0 in its last, which holds the 16 streams of a
+    // CU within a quarter of each other and shortens the tail.
+    const uint64_t quarter = (bytes >> 2) + 1;
+    int prio_now = -1;
     while (i < bytes && err == 0) {
+        {
+            const int q = (int)(i / quarter);                  // 0..3
+            if (q != prio_now) {
+                prio_now = q;
+                if (q == 0) { __builtin_amdgcn_s_setprio(3); }
+                else if (q == 1) { __builtin_amdgcn_s_setprio(2); }
+                else if (q == 2) { __builtin_amdgcn_s_setprio(1); }
+                else { __builtin_amdgcn_s_setprio(0); }
+            }
+        }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
                             ntok > (1u << 24);
         if (lit.lut_ok == 0) { lit.build_lut(lane); }

@@ -239,7 +239,20 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 #else
 #define ES(k)
 #endif
+    // streams that are ahead step back (see entropy_decode_kernel): priority 3 -> 0 by quarters
+    const uint32_t quarter = (count >> 2) + 1;
+    int prio_now = -1;
     while (cursor < count && err == 0) {
+        {
+            const int q = (int)(cursor / quarter);             // 0..3
+            if (q != prio_now) {
+                prio_now = q;
+                if (q == 0) { __builtin_amdgcn_s_setprio(3); }
+                else if (q == 1) { __builtin_amdgcn_s_setprio(2); }
+                else if (q == 2) { __builtin_amdgcn_s_setprio(1); }
+                else { __builtin_amdgcn_s_setprio(0); }
+            }
+        }
         if (cursor + kWave > sbase + shave && sbase + shave < count) {   // restage from the cursor
             sbase = cursor;
             const uint32_t left = count - sbase;
