@@ -254,7 +254,8 @@ void index_match_kernel(const uint8_t* __restrict__ in,
     // gathered at random.  Measured (PMC, 1 GiB batch): FETCH 185 GB with the stream on the
     // fast grid axis, 16.3 GB with consecutive workgroups sharing a stream across all eight
     // L2s, 3.5 GB with this mapping (61 -> 38 ms).  The 4-byte scatter into match[] is NOT
-    // helped by it: WRITE_SIZE stayed at 41-47 GB for 4 GB of match words (open item).
+    // helped by it: WRITE_SIZE stayed at 41-47 GB for 4 GB of match words.  Measured ceiling
+    // of fixing that: the same kernel storing to match[rank] (contiguous) takes 30 ms.
     const uint32_t xcd = blockIdx.x % (uint32_t)kXcds;
     const uint32_t local = blockIdx.x / (uint32_t)kXcds;
     const uint32_t b = (local / groups) * (uint32_t)kXcds + xcd;
@@ -321,6 +322,14 @@ struct ParseLds {
 
 __device__ __forceinline__ uint32_t parse_slot(uint32_t k) { return k + (k / (uint32_t)kChunk); }
 
+// how far a token reaches: its match length, 1 for a literal.  Match words come from
+// index_match_kernel (length >= 3); the floor of 1 is there so that the walks below end
+// whatever the table holds -- a word with a zero length field must not stall a wave.
+__device__ __forceinline__ uint32_t parse_step(uint32_t w) {
+    const uint32_t len = w >> 16;
+    return len != 0 ? len : 1u;
+}
+
 __global__ __launch_bounds__(kWave)
 void index_parse_kernel(const uint8_t* __restrict__ in,
                         const uint64_t* __restrict__ in_off,
@@ -368,7 +377,7 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
         while (p < room) {
             guess |= 1ull << p;
             const uint32_t w = row[p];
-            p += w != 0 ? (w >> 16) : 1u;
+            p += parse_step(w);
         }
         const uint32_t guess_out = lo + p;           // where the guess leaves the chunk (>= lo + room)
 
@@ -394,7 +403,7 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
                 }
                 real |= 1ull << q;
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.m[l * kChunkRow + (int)q]);
-                q += w != 0 ? (w >> 16) : 1u;
+                q += parse_step(w);
                 if (q >= croom) { e = clo + q; break; }
             }
             if (lane == l) { mine = real; }
