@@ -187,6 +187,11 @@ SQZ_API int sqz_hip_lz77_blocks_ex(const void* d_in, const uint64_t* d_in_off, u
                                    uint32_t window, uint32_t* d_tokens,
                                    uint32_t* d_token_count, int finder,
                                    void* d_work, uint64_t work_bytes, void* stream);
+/* stage 2 alone, on the caller's token words.  Every word is checked (a byte, or len 3..257 and
+ * dist 1..32767, no stray bits) and a block may not hold more tokens than it has slots: a
+ * violation fails that block with err[b] = EINVAL, other blocks are unaffected.  Whether the
+ * tokens describe a consistent text (distances within what precedes them, lengths adding up) is
+ * the caller's business: an inconsistent sequence encodes to a stream the decoder rejects. */
 SQZ_API int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
                                    const uint32_t* d_token_count, uint32_t n,
                                    void* d_out, const uint64_t* d_out_off,

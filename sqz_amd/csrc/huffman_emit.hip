@@ -182,6 +182,15 @@ __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& p
     if (lit.fault | pos.fault) { err = kE2BIG; }
 }
 
+// A token word as stage 1 writes it: a byte, or 0x80000000 | len << 16 | dist with len 3..257
+// and dist 1..32767.  The token arrays of sqz_hip_huffman_blocks come from the caller, and a
+// length or distance outside the code tables would index past the trees.
+__device__ __forceinline__ bool token_ok(uint32_t t) {
+    if ((t & kTokMatch) == 0) { return t <= 0xFFu; }
+    const uint32_t len = (t >> 16) & 0x7FFFu, dist = t & 0xFFFFu;
+    return len >= (uint32_t)kLenMin && len <= (uint32_t)kLenMax && dist >= 1u && dist <= 0x7FFFu;
+}
+
 // Tokens of stage 1 -> bit stream.  Up to 64 tokens per step, one per lane
 // (sqz_device.h: bump_lanes); a step shrinks to the tokens in front of the first
 // unseen symbol, halves when the no-restructure tests fail, and a single token that
@@ -213,7 +222,9 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     __syncthreads();
 
     const uint32_t* tok = tokens + uni64(tok_off[b]);
-    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+    uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_count[b]);
+    const bool too_many = (uint64_t)count > uni64(tok_off[b + 1]) - uni64(tok_off[b]);   // one slot per byte
+    if (too_many) { count = 0; }
 
     BitQueue q;
     q.lds = &lds;
@@ -226,6 +237,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     q.error = 0;
     int err = 0;
 
+    if (too_many) { err = kEINVAL; }
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
     if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
 
@@ -263,7 +275,9 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         // ---- this lane's token ------------------------------------------------------
         const uint32_t idx = cursor - sbase + (uint32_t)lane;
         const bool valid = idx < shave;
-        const uint32_t t = valid ? lds.strip[idx] : 0u;
+        const uint32_t traw = valid ? lds.strip[idx] : 0u;
+        const bool wellformed = token_ok(traw);
+        const uint32_t t = wellformed ? traw : 0u;                     // a malformed word is never decoded
         const bool is_match = (t & kTokMatch) != 0;
         Code lc = {0, 0, 0}, pc = {0, 0, 0};
         int a = (int)(t & 0xFFu), bsym = -1;
@@ -276,7 +290,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         // unseen symbols need the NYT escape + an insert: they end the step
         const uint32_t da = valid ? (uint32_t)(link[a] >> 52) & 0x3Fu : 1u;
         const uint32_t db = (valid && is_match) ? (uint32_t)(link[bsym] >> 52) & 0x3Fu : 1u;
-        const uint64_t unseen = __ballot(valid && (da == 0 || db == 0));
+        const uint64_t unseen = __ballot(valid && (da == 0 || db == 0 || !wellformed));
         const uint64_t vmask = __ballot(valid);
         int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
@@ -308,7 +322,8 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         if (m < offered || offered == 0 || frozen) {
             // the token the step stopped at (NYT escape / the tree restructures / frozen tree):
             // one symbol at a time, always exact
-            const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)t, m);
+            const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)traw, m);
+            if (!token_ok(tx)) { err = kEINVAL; break; }
             emit_token(q, lit, pos, tx, lane, err);
             if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
             cursor += 1;

@@ -362,3 +362,56 @@ def test_one_large_stream(sq, batch):
     batch.decode_blocks(out, out_off, 1, back, off, derr)
     torch.cuda.synchronize()
     assert int(derr[0]) == 0 and bool((back == d_in).all())
+
+
+def test_caller_tokens_are_validated(sq, batch):
+    """sqz_hip_huffman_blocks takes the CALLER's token words: a length or distance outside the
+    code tables, stray bits, or more tokens than the block has bytes must fail that block with
+    EINVAL -- not index past the trees or stall a wave -- and leave its neighbours alone."""
+    import errno
+    import torch
+    from sqz_amd import _native as N
+    data = O.corpus("laozi.txt")[:6000]
+    good = O.tokens(data, 1 << 12)
+    bad_words = [0x80000000 | (1 << 16) | 5,        # len 1
+                 0x80000000 | (300 << 16) | 5,      # len 300
+                 0x80000000 | (4 << 16) | 0,        # dist 0
+                 0x80000000 | (4 << 16) | 0x8000,   # dist 32768
+                 0x00000141,                        # a "literal" wider than a byte
+                 0xC0000000 | (4 << 16) | 5]        # stray bit 30
+    cases = [("good", good, len(good))]
+    for k, w in enumerate(bad_words):
+        t = good.copy()
+        t[len(t) // 2 + k] = w
+        cases.append((f"bad{k}", t, len(t)))
+    cases.append(("too many", good, len(data) + 1))
+    cases.append(("good again", good, len(good)))
+    n = len(cases)
+    slots = len(data)
+    off = batch.uniform_offsets(n, slots)
+    toks = np.zeros(n * slots + 64, np.uint32)
+    counts = np.zeros(n, np.uint32)
+    for b, (_, t, c) in enumerate(cases):
+        toks[b * slots:b * slots + len(t)] = t
+        counts[b] = c
+    d_tok = torch.tensor(toks.view(np.int32), device="cuda")
+    d_cnt = torch.tensor(counts.view(np.int32), device="cuda")
+    cap = sq.bound(slots)
+    out_off = batch.uniform_offsets(n, cap)
+    out = torch.zeros(n * cap, dtype=torch.uint8, device="cuda")
+    out_bytes = torch.zeros(n, dtype=torch.int64, device="cuda")
+    err = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    rc = N.lib().sqz_hip_huffman_blocks(d_tok.data_ptr(), off.data_ptr(), d_cnt.data_ptr(), n,
+                                        out.data_ptr(), out_off.data_ptr(), out_bytes.data_ptr(),
+                                        err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    err = err.cpu().numpy()
+    want = O.encode(data, 12, header=False)
+    for b, (name, _, _) in enumerate(cases):
+        if name.startswith("good"):
+            assert err[b] == 0, name
+            got = bytes(out[b * cap:b * cap + int(out_bytes[b])].cpu().numpy())
+            assert got == want, name
+        else:
+            assert err[b] == errno.EINVAL, (name, err[b])
