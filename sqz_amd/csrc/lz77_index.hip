@@ -34,7 +34,10 @@ constexpr int kSortWaves = kSortThreads / kWave;
 
 constexpr int kSortTile = 4 * kSortThreads;      // elements per workgroup tile (4 rows of 64 per wave)
 
-// One pass = a histogram sweep (global digit bases) and a scatter sweep.  The scatter does
+// The three digit histograms do not depend on the order of the elements (a position's key
+// bytes are fixed), so one sweep over the stream's BYTES gives all three; each pass is then a
+// single sweep over the elements (there used to be a counting sweep per pass as well: 24 GB of
+// element reads per batch instead of 12).  The scatter does
 // not write elements where they fall: every 4096-element tile is first ordered by digit in
 // LDS (stable: wave order, then row and lane order inside a wave), then copied out, so a
 // digit's elements of one tile leave as one contiguous run (16 elements = one line on
@@ -42,14 +45,13 @@ constexpr int kSortTile = 4 * kSortThreads;      // elements per workgroup tile 
 // bucket kept ~256 half-filled lines open per wave -- 16 MB of open lines per XCD against
 // 4 MB of L2 -- and they left as partial-line writes: 53 GB written for 12 GB of elements.
 struct SortLds {
-    uint32_t elem[kSortTile];            // the tile in digit order; the histogram sweep's counters alias it
+    uint32_t elem[kSortTile];            // the tile in digit order
     uint8_t  dig[kSortTile];             // digit per tile slot
     uint16_t cnt[kSortWaves][256];       // per tile: elements of (wave, digit) so far -> offset inside the digit's run
-    uint32_t gbase[256];                 // where the next tile's run of digit d goes
+    uint32_t gbase[3][256];              // per pass: where the next tile's run of digit d goes
     uint32_t tstart[256];                // tile slot where digit d's run starts
     uint32_t total[256];
 };
-static_assert(sizeof(uint32_t) * kSortTile >= sizeof(uint32_t) * kSortWaves * 256, "histogram counters alias elem[]");
 
 struct __attribute__((packed)) U32u { uint32_t v; };
 
@@ -94,20 +96,38 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
     const uint32_t count = (uint32_t)(bytes - 2);             // positions with a 3-byte prefix
     uint32_t* const pa = buf_a + in_off[b];
     uint32_t* const pb = buf_b + in_off[b];
-    uint16_t* const cache = reinterpret_cast<uint16_t*>(tmp + in_off[b]);   // bytes p, p+1 per row
+    (void)tmp;                                                // (was the per-row byte cache of the counting sweeps)
     // blocks up to 16 MB carry byte 0 of the key in the element's top 8 bits from
     // pass 1 to pass 2, so only pass 1 gathers at random
     const bool carry = bytes <= (1u << 24);
-    uint32_t (*const hist)[256] = reinterpret_cast<uint32_t (*)[256]>(lds.elem);
+    // ---- all three histograms from the bytes: pass p sorts by byte 2 - p of the key ---------
+    for (int d = tid; d < 3 * 256; d += kSortThreads) { (&lds.gbase[0][0])[d] = 0; }
+    __syncthreads();
+    for (uint32_t k = (uint32_t)tid; k < count; k += (uint32_t)kSortThreads) {
+        atomicAdd(&lds.gbase[0][src[k + 2]], 1u);
+        atomicAdd(&lds.gbase[1][src[k + 1]], 1u);
+        atomicAdd(&lds.gbase[2][src[k]], 1u);
+    }
+    __syncthreads();
+    if (wave < 3) {                                        // exclusive scans: counts -> bases
+        uint32_t* const g = lds.gbase[wave];
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = g[4 * lane + j]; sum += v[j]; }
+        uint32_t excl = wave_scan(sum) - sum;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { g[4 * lane + j] = excl; excl += v[j]; }
+    }
+    __syncthreads();
 
     for (int pass = 0; pass < 3; pass++) {
         // pass 0: identity -> A by byte 2 ; pass 1: A -> B by byte 1 ; pass 2: B -> A by byte 0
         const uint32_t* from = pass == 1 ? pa : pb;
         uint32_t* to = pass == 1 ? pb : pa;
+        uint32_t* const gbase = lds.gbase[pass];
 
-        // element k of the input order belongs to tile k / 4096, wave (k / 256) % 16, row (k / 64) % 4:
-        // both sweeps use this mapping, so a thread meets the same elements twice
-        auto load_rows = [&](uint32_t tile, bool first, uint32_t (&elem)[4], uint32_t (&digit)[4], bool (&valid)[4]) {
+        // element k of the input order belongs to tile k / 4096, wave (k / 256) % 16, row (k / 64) % 4
+        auto load_rows = [&](uint32_t tile, uint32_t (&elem)[4], uint32_t (&digit)[4], bool (&valid)[4]) {
             uint32_t pos[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -117,18 +137,11 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t k = tile + (uint32_t)(wave * 256 + j * kWave + lane);
                 digit[j] = 0; elem[j] = pos[j];
                 if (valid[j]) {
                     if (pass == 0) { digit[j] = src[pos[j] + 2]; }
-                    else if (pass == 1) {
-                        uint32_t w;
-                        if (first) {                   // the one random gather: bytes p and p+1
-                            w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
-                            cache[k] = (uint16_t)w;
-                        } else {
-                            w = cache[k];              // written by this thread in the histogram sweep
-                        }
+                    else if (pass == 1) {          // the one random gather: bytes p and p+1
+                        const uint32_t w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
                         digit[j] = w >> 8;
                         if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
                     } else {
@@ -139,46 +152,13 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
             }
         };
 
-        // ---- histogram of the whole stream (wave-private counters, no atomics) --------
-        for (int d = lane; d < 256; d += kWave) { hist[wave][d] = 0; }
-        for (uint32_t tile = 0; tile < count; tile += (uint32_t)kSortTile) {
-            uint32_t elem[4], digit[4];
-            bool valid[4];
-            load_rows(tile, true, elem, digit, valid);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint64_t peers = peers_of(digit[j], valid[j]);
-                if (valid[j] && lanes_below(peers) == 0) {
-                    hist[wave][digit[j]] += (uint32_t)__builtin_popcountll(peers);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 256) {
-            uint32_t run = 0;
-            for (int w = 0; w < kSortWaves; w++) { run += hist[w][tid]; }
-            lds.total[tid] = run;
-        }
-        __syncthreads();
-        if (wave == 0) {                                   // exclusive scan of 256 totals
-            uint32_t v[4], s = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { v[j] = lds.total[4 * lane + j]; s += v[j]; }
-            uint32_t incl = s;
-            incl = wave_scan(incl);
-            uint32_t excl = incl - s;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { lds.gbase[4 * lane + j] = excl; excl += v[j]; }
-        }
-        __syncthreads();
-
         // ---- scatter, tile by tile ------------------------------------------------------
         for (uint32_t tile = 0; tile < count; tile += (uint32_t)kSortTile) {
             const uint32_t n_tile = count - tile < (uint32_t)kSortTile ? count - tile : (uint32_t)kSortTile;
             for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
             uint32_t elem[4], digit[4], wrank[4];
             bool valid[4];
-            load_rows(tile, false, elem, digit, valid);
+            load_rows(tile, elem, digit, valid);
 #pragma unroll
             for (int j = 0; j < 4; j++) {                      // rows in order: stability
                 const uint64_t peers = peers_of(digit[j], valid[j]);
@@ -228,12 +208,12 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
                 const uint32_t slot = (uint32_t)(j * kSortThreads + tid);
                 if (slot < n_tile) {
                     const uint32_t d = lds.dig[slot];
-                    const uint32_t dest = lds.gbase[d] + (slot - lds.tstart[d]);
+                    const uint32_t dest = gbase[d] + (slot - lds.tstart[d]);
                     if (dest < count) { to[dest] = lds.elem[slot]; }   // always: a permutation of [0, count)
                 }
             }
             __syncthreads();
-            if (tid < 256) { lds.gbase[tid] += tcount; }
+            if (tid < 256) { gbase[tid] += tcount; }
         }
         // the next pass reads what other waves of this workgroup wrote
         __threadfence_block();
