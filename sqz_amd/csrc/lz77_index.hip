@@ -249,14 +249,76 @@ void index_match_kernel(const uint8_t* __restrict__ in,
     const uint32_t* S = sorted + in_off[b];
     uint32_t* M = match + in_off[b];
 
-    for (uint32_t r = group * blockDim.x + threadIdx.x; r < count; r += groups * blockDim.x) {
-        const uint32_t i = S[r];
+    const int lane = (int)(threadIdx.x & (kWave - 1));
+    for (uint32_t r0 = group * blockDim.x + (threadIdx.x - (uint32_t)lane); r0 < count; r0 += groups * blockDim.x) {
+        const uint32_t r = r0 + (uint32_t)lane;              // a wave owns 64 consecutive ranks
+        const bool valid = r < count;
+        const uint32_t i = valid ? S[r] : 0u;
         const uint32_t cap = (n - i) < (uint32_t)kLenMax ? (n - i) : (uint32_t)kLenMax;
         const uint32_t reach = i < window - 1 ? i : window - 1;
         // i <= n-3; a 4-byte load may touch byte i+3 == n only for the last position
         const uint32_t key = (i + 4 <= n) ? (load_u32_unaligned(src + i) & 0x00FFFFFFu)
             : ((uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16));
         uint32_t best = 0, dist = 0;
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+        if (__ballot(valid && key == key0 && i + 16 <= n) == ~0ull) {
+            // ---- the whole wave sits inside one run of equal keys (a frequent 3-byte string) ---
+            // Its lanes walk the same candidates, one rank apart.  Walk them ONCE: the candidate's
+            // position comes from a register page of sorted positions (v_readlane), its bytes from
+            // one broadcast load, and every lane compares them with its own first 16 bytes, held in
+            // registers -- no per-lane gathers.  Same order (nearest first), same strict >.
+            const uint32_t own0 = load_u32_unaligned(src + i), own1 = load_u32_unaligned(src + i + 4);
+            const uint32_t own2 = load_u32_unaligned(src + i + 8), own3 = load_u32_unaligned(src + i + 12);
+            bool done = false;
+            uint32_t page_base = r0, page = i;               // page = sorted positions of ranks [page_base, +64)
+            for (int64_t c = (int64_t)r0 + kWave - 2; c >= 0; c--) {
+                if (c < (int64_t)page_base) {
+                    page_base -= (uint32_t)kWave;            // r0 is a multiple of 64: so is every page
+                    page = S[page_base + (uint32_t)lane];
+                }
+                const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)page, (int)(c - (int64_t)page_base));
+                const bool below = (int64_t)r > c;           // the candidate comes before my position
+                const uint32_t d = i - pc;
+                if (below && d > reach) { done = true; }     // everything further is farther
+                if (__ballot(!done) == 0) { break; }
+                const uint8_t* cp = src + pc;
+                // its key first: a rank in front of the run can be any position, also the last one
+                const uint32_t c0 = (pc + 4 <= n) ? load_u32_unaligned(cp)
+                    : ((uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16));
+                if ((c0 & 0x00FFFFFFu) != key0) { break; }   // left the run: so have all earlier ranks
+                // inside the run positions grow with the rank: pc < lane 63's i, so pc + 16 <= n
+                const uint32_t c1 = load_u32_unaligned(cp + 4);
+                const uint32_t c2 = load_u32_unaligned(cp + 8), c3 = load_u32_unaligned(cp + 12);
+                const uint32_t x0 = own0 ^ c0, x1 = own1 ^ c1, x2 = own2 ^ c2, x3 = own3 ^ c3;
+                uint32_t len = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3)
+                             : x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
+                             : x2 != 0 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
+                             : x3 != 0 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+                const bool want = below && !done;
+                if (want && len == 16u && cap > 16u) {       // longer than the registers hold
+                    uint32_t k = 16;
+                    while (k < cap) {
+                        if (i + k + 4 <= n) {
+                            const uint32_t x = load_u32_unaligned(cp + k) ^ load_u32_unaligned(src + i + k);
+                            if (x != 0) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                            k += 4;
+                        } else {
+                            if (cp[k] != src[i + k]) { break; }
+                            k++;
+                        }
+                    }
+                    len = k;
+                }
+                if (len > cap) { len = cap; }
+                if (want && len > best) {                    // strictly longer: nearest among equals
+                    best = len; dist = d;
+                    if (best >= cap) { done = true; }
+                }
+            }
+            M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
+            continue;
+        }
+        if (!valid) { continue; }
         for (uint32_t q = r; q > 0 && best < cap; ) {
             q--;
             const uint32_t p = S[q];                       // p < i inside a run
