@@ -1,3 +1,6 @@
+// tools/microbench/issue.hip -- cycles per instruction of a lone wave: dependent / independent VALU, SALU, v_readlane -> SALU chains, exec-mask regions.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench/issue tools/microbench/issue.hip ; run on an MI355X.
+// The figures quoted in DESIGN.md section 5 come from this program.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,3 +1,6 @@
+// tools/microbench/lds_atomic.hip -- cycles per LDS instruction of a lone wave: atomics (returning or not) and reads, with k lanes on one address.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench/lds_atomic tools/microbench/lds_atomic.hip ; run on an MI355X.
+// The figures quoted in DESIGN.md section 5 come from this program.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

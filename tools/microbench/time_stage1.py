@@ -1,4 +1,5 @@
-"""time the stage-1 kernels alone (sort / match / parse) on the bench batch"""
+"""tools/microbench/time_stage1.py -- time the stage-1 kernels alone (sort / match / parse) on the
+bench batch through sqz_hip_lz77_blocks_ex (python tools/microbench/time_stage1.py, needs an MI355X)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, sqz_amd
