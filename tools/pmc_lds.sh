@@ -1,4 +1,5 @@
 #!/bin/bash
+# LDS activity / conflict counters of the kernels (separate PMC passes, kernel trace only)
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p $R/gpurun_out/pmc2
