@@ -12,6 +12,7 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 /* ------------------------------------------------------------------ */
 /* alphabet constants: squeeze.h:9-25                                  */
@@ -296,6 +297,36 @@ static int tree_insert(tree* t, int32_t i) {
     return ok;
 }
 
+#ifdef SQZO_CHECK_INVARIANTS
+/* Opt-in self-check (make -C oracle check-invariants): two properties the GPU kernels'
+ * batched update relies on, asserted after EVERY update on whatever input is run:
+ *   1. at rest every sibling pair is ordered, freq[lo] <= freq[hi] (the climb of
+ *      huffman_frequency_changed re-orders each level it passes, huffman.h:132-142);
+ *   2. a node that hangs below the root has a sibling unless the tree holds one leaf. */
+#include <stdlib.h>
+static void tree_check(const tree* t) {
+    const int32_t m = 2 * t->n - 1, root = m - 1;
+    int32_t leaves = 0;
+    for (int32_t v = 0; v < t->n; v++) { if (t->up[v] >= 0) { leaves++; } }
+    for (int32_t v = t->n; v < m; v++) {
+        if (v != root && t->up[v] < 0) { continue; }            /* unused internal id */
+        const int32_t l = t->lo[v], h = t->hi[v];
+        if (l >= 0 && h >= 0 && t->freq[l] > t->freq[h]) {
+            fprintf(stderr, "invariant 1 broken at node %d: lo %llu > hi %llu\n", v,
+                    (unsigned long long)t->freq[l], (unsigned long long)t->freq[h]);
+            abort();
+        }
+        if (leaves >= 2 && (l < 0 || h < 0)) {
+            fprintf(stderr, "invariant 2 broken at node %d: a child without a sibling (%d leaves)\n", v, leaves);
+            abort();
+        }
+    }
+}
+#define TREE_CHECK(t) tree_check(t)
+#else
+#define TREE_CHECK(t) ((void)0)
+#endif
+
 static void tree_bump(tree* t, int32_t i) { /* huffman.h:218-235 */
     if (t->up[i] == -1) {
         (void)tree_insert(t, i);
@@ -306,6 +337,7 @@ static void tree_bump(tree* t, int32_t i) { /* huffman.h:218-235 */
     } else {
         t->complete = 1;
     }
+    TREE_CHECK(t);
 }
 
 /* ------------------------------------------------------------------ */

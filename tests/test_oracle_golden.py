@@ -153,3 +153,34 @@ def test_against_reference_build():
         a, ia = O.tree_run(O.REF, "sqz_ref_tree_run", n, syms)
         b, ib = O.tree_run(O.ORACLE, "sqzo_tree_run", n, syms)
         assert all((x == y).all() for x, y in zip(a, b)) and (ia == ib).all()
+
+
+def test_tree_invariants_the_kernels_rely_on():
+    """The batched update in the HIP kernels (sqz_device.h: LaneWalk::level) drops two tests
+    because of two properties of the tree at rest: every sibling pair is ordered (lo <= hi) and
+    every node below the root has a sibling once the tree holds two leaves.  The oracle built
+    with -DSQZO_CHECK_INVARIANTS asserts both after EVERY update (it aborts otherwise)."""
+    import ctypes as C
+    import random
+    import subprocess
+    subprocess.check_call(["make", "-C", O.ODIR, "-s", "check-invariants"])
+    L = C.CDLL(os.path.join(O.ODIR, "liboracle_check.so"))
+    L.sqzo_encode.restype = C.c_int
+    L.sqzo_encode.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
+                              C.POINTER(C.c_uint64)]
+
+    def enc(data, window):
+        out = C.create_string_buffer(2 * len(data) + 4096)
+        nb = C.c_uint64(0)
+        assert L.sqzo_encode(data, len(data), window, 0, out, len(out), C.byref(nb)) == 0
+
+    for name in ("laozi.txt", "confucius.txt", "x64.elf", "mandrill.bmp"):
+        enc(O.corpus(name)[:40000], 1 << 12)
+    enc(O.zipf_block(0, 32768), 1 << 12)
+    rng = random.Random(5)
+    for _ in range(12):
+        n = rng.choice([1, 2, 3, 50, 999, 5000])
+        alpha = rng.choice([2, 4, 16, 256])
+        enc(bytes(rng.randrange(alpha) for _ in range(n)), rng.choice([32, 1 << 10]))
+    enc(bytes(20000), 1 << 12)
+    enc(b"abc" * 7000, 1 << 12)
