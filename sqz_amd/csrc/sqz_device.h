@@ -968,10 +968,13 @@ struct LaneWalk {
         const uint32_t kids1 = (uint32_t)(link[base + (int)i1] >> 32);
         const uint32_t kids2 = (uint32_t)(link[base + (int)i2] >> 32);
         const uint64_t w3 = link[base + (int)i3];
+        // the root is not counted: nothing ever compares its count (it is no one's child,
+        // sibling or uncle; the climbs recompute it from its children), and it is the one
+        // node every lane would hit
         uint32_t old0 = 0, old1 = 0, old2 = 0;
-        if (live) { old0 = atomicAdd(&freq[base + (int)c], kCntOne); }
-        if (v1) { old1 = atomicAdd(&freq[base + (int)i1], kCntOne); }
-        if (v2) { old2 = atomicAdd(&freq[base + (int)i2], kCntOne); }
+        if (v1) { old0 = atomicAdd(&freq[base + (int)c], kCntOne); }
+        if (v2) { old1 = atomicAdd(&freq[base + (int)i1], kCntOne); }
+        if (v3) { old2 = atomicAdd(&freq[base + (int)i2], kCntOne); }
         level(freq, c, old0, kids1, v1);
         level(freq, p1, old1, kids2, v2);
         level(freq, p2, old2, (uint32_t)(w3 >> 32), v3);
@@ -985,9 +988,9 @@ struct LaneWalk {
         const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
         const uint32_t i1 = v1 ? p1 : c, i2 = v2 ? p2 : c, i3 = v3 ? p3 : c;
         const uint64_t w3 = link[base + (int)i3];
-        if (live) { atomicAdd(&freq[base + (int)c], delta); }
-        if (v1) { atomicAdd(&freq[base + (int)i1], delta); }
-        if (v2) { atomicAdd(&freq[base + (int)i2], delta); }
+        if (v1) { atomicAdd(&freq[base + (int)c], delta); }        // not the root (see count3)
+        if (v2) { atomicAdd(&freq[base + (int)i1], delta); }
+        if (v3) { atomicAdd(&freq[base + (int)i2], delta); }
         live = v3; c = i3; w = w3;
     }
 };
