@@ -350,7 +350,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         int wa, wb;
         int done = 0;
         ST_SEC(2)
-        if (m > 0) { done = bump_lanes(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        if (m > 0) { done = bump_lanes<false>(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
         ST_SEC(3)
         uint64_t resume = bit0;
         if (done > 0) {

@@ -299,7 +299,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         int wa = 0, wb = 0;
         const int offered = m;
         ES(0)
-        if (m >= 1 && !frozen) { m = bump_lanes(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
+        if (m >= 1 && !frozen) { m = bump_lanes<true>(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
         else { m = 0; }
         ES(1)
         if (m >= 1) {

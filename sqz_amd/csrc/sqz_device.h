@@ -945,6 +945,7 @@ struct LaneWalk {
     // of a seen symbol always has a sibling, and lo <= hi for every pair -- so a hi child needs
     // no test against its own sibling (the reference's swap can only be triggered from the lo
     // side), only against its uncle, which is the next level's sibling.
+    template <bool kWantCode>
     __device__ __forceinline__ void level(const uint32_t* freq, uint32_t node, uint32_t old, uint32_t kids,
                                           bool valid) {
         const uint32_t lo = kids & 0x3FFu, hi = (kids >> 10) & 0x3FFu;
@@ -954,13 +955,17 @@ struct LaneWalk {
         const uint32_t reach = (old & kCountMask) + (old >> kCntShift) + 1u;   // my count of the node after my add
         bad |= valid & !is_hi & (reach > f0s);                           // a lo child overtaking its sibling
         bad |= valid & prev_hi & (prev_reach > f0s);                     // the hi child below overtaking its uncle
-        code |= ((valid & is_hi) ? 1u : 0u) << k;
-        k += valid ? 1 : 0;
-        prev_hi = valid ? is_hi : prev_hi;
-        prev_reach = valid ? reach : prev_reach;
+        if (kWantCode) {
+            code |= ((valid & is_hi) ? 1u : 0u) << k;
+            k += valid ? 1 : 0;
+        }
+        prev_hi = is_hi;             // past the end of a chain these are never looked at again:
+        prev_reach = reach;          // every later level is invalid too and masks its tests
     }
 
-    // sweep 1: count + test + code, three levels
+    // sweep 1: count + test (+ code: the encoder emits it, the decoder has no use for it),
+    // three levels
+    template <bool kWantCode>
     __device__ __forceinline__ void count3(const uint64_t* link, uint32_t* freq) {
         const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
         const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
@@ -975,10 +980,10 @@ struct LaneWalk {
         if (v1) { old0 = atomicAdd(&freq[base + (int)c], kCntOne); }
         if (v2) { old1 = atomicAdd(&freq[base + (int)i1], kCntOne); }
         if (v3) { old2 = atomicAdd(&freq[base + (int)i2], kCntOne); }
-        level(freq, c, old0, kids1, v1);
-        level(freq, p1, old1, kids2, v2);
-        level(freq, p2, old2, (uint32_t)(w3 >> 32), v3);
-        if (k >= 29) { bad = true; }                                     // never: left to the serial path
+        level<kWantCode>(freq, c, old0, kids1, v1);
+        level<kWantCode>(freq, p1, old1, kids2, v2);
+        level<kWantCode>(freq, p2, old2, (uint32_t)(w3 >> 32), v3);
+        if (kWantCode && k >= 29) { bad = true; }                        // never: left to the serial path
         live = v3; c = i3; w = w3;
     }
 
@@ -997,6 +1002,7 @@ struct LaneWalk {
 
 // Whole wave: lanes [0, m) offer their symbols (a, then b; unified leaf ids, -1 = none).
 // Returns how many leading tokens were applied (0..m); codes/depths are valid for those.
+template <bool kWantCode>
 __device__ __forceinline__ int bump_lanes(uint64_t* link, uint32_t* freq, int lane, int m, int a, int b,
                                           uint64_t& code_a, int& depth_a, uint64_t& code_b, int& depth_b) {
     const bool take = lane < m;
@@ -1010,10 +1016,14 @@ __device__ __forceinline__ int bump_lanes(uint64_t* link, uint32_t* freq, int la
 #endif
     wa.open(link, la);
     wb.open(link, lb);
+    if (!kWantCode) {                                                    // the walk does not count its levels: ask the leaf
+        wa.bad = wa.live && ((uint32_t)(wa.w >> 52) & 0x3Fu) >= 29u;
+        wb.bad = wb.live && ((uint32_t)(wb.w >> 52) & 0x3Fu) >= 29u;
+    }
     BL_SEC(0)
     while (__ballot(wa.live | wb.live) != 0) {
-        wa.count3(link, freq);
-        if (__ballot(wb.live) != 0) { wb.count3(link, freq); }
+        wa.template count3<kWantCode>(link, freq);
+        if (__ballot(wb.live) != 0) { wb.template count3<kWantCode>(link, freq); }
 #ifdef SQZ_STATS
         if (blockIdx.x == 1 && threadIdx.x == 0) { g_st[4] += 1; }
 #endif
