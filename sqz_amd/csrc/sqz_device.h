@@ -991,11 +991,11 @@ struct LaneWalk {
     __device__ __forceinline__ void add3(const uint64_t* link, uint32_t* freq, uint32_t delta) {
         const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
         const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
-        const uint32_t i1 = v1 ? p1 : c, i2 = v2 ? p2 : c, i3 = v3 ? p3 : c;
+        const uint32_t i3 = v3 ? p3 : c;
         const uint64_t w3 = link[base + (int)i3];
-        if (v1) { atomicAdd(&freq[base + (int)c], delta); }        // not the root (see count3)
-        if (v2) { atomicAdd(&freq[base + (int)i1], delta); }
-        if (v3) { atomicAdd(&freq[base + (int)i2], delta); }
+        if (v1) { atomicAdd(&freq[base + (int)c], delta); }         // not the root (see count3)
+        if (v2) { atomicAdd(&freq[base + (int)p1], delta); }
+        if (v3) { atomicAdd(&freq[base + (int)p2], delta); }
         live = v3; c = i3; w = w3;
     }
 };
