@@ -20,14 +20,12 @@
 
 namespace sqzk {
 
-constexpr int kTokStrip = 128;        // token words staged in LDS per refill
 constexpr int kQueue = 32;            // fields of the one-at-a-time path per pack
 constexpr int kQueueRoom = 8;         // a token adds at most 6 fields (+2 for a 63-bit code)
 constexpr int kImageWords = 62;       // 64 lanes x <= 58 bits + carry
 
 struct EmitLds {
     EntropyLds entropy;
-    uint32_t   strip[kTokStrip];
     uint64_t   field[kQueue];         // width << 32 | value   (width 1..32)
     uint64_t   image[kImageWords];    // packed bits of one batch, stream order = MSB first
 };
@@ -243,7 +241,12 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 
     uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
     uint32_t* const freq = lds.entropy.lit_freq;
-    uint32_t cursor = 0, sbase = 0, shave = 0;        // strip holds tokens [sbase, sbase+shave)
+    uint32_t cursor = 0;
+    // The tokens [cursor, cursor + 128) sit in two registers per lane.  After a step the window is
+    // shifted by what the step consumed (two ds_bpermute) and its second half reloaded from memory:
+    // that load is in flight during the whole next step instead of being waited for.
+    uint32_t win0 = (uint32_t)lane < count ? tok[lane] : 0u;
+    uint32_t win1 = (uint32_t)lane + (uint32_t)kWave < count ? tok[kWave + lane] : 0u;
 #ifdef SQZ_STATS
     uint64_t es[4] = {0, 0, 0, 0}, es_last = __builtin_readcyclecounter(), es_begin = es_last;
     uint32_t es_steps = 0, es_exact = 0;
@@ -265,17 +268,10 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                 else { __builtin_amdgcn_s_setprio(0); }
             }
         }
-        if (cursor + kWave > sbase + shave && sbase + shave < count) {   // restage from the cursor
-            sbase = cursor;
-            const uint32_t left = count - sbase;
-            shave = left < (uint32_t)kTokStrip ? left : (uint32_t)kTokStrip;
-            for (uint32_t k = lane; k < shave; k += kWave) { lds.strip[k] = tok[sbase + k]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        }
         // ---- this lane's token ------------------------------------------------------
-        const uint32_t idx = cursor - sbase + (uint32_t)lane;
-        const bool valid = idx < shave;
-        const uint32_t traw = valid ? lds.strip[idx] : 0u;
+        const uint32_t step_start = cursor;
+        const bool valid = cursor + (uint32_t)lane < count;
+        const uint32_t traw = win0;                                    // 0 past the end
         const bool wellformed = token_ok(traw);
         const uint32_t t = wellformed ? traw : 0u;                     // a malformed word is never decoded
         const bool is_match = (t & kTokMatch) != 0;
@@ -335,6 +331,15 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 #ifdef SQZ_STATS
         es_steps++;
 #endif
+        {   // slide the window by the 1..64 tokens this step consumed
+            const uint32_t adv = cursor - step_start;
+            const int from = ((lane + (int)adv) & (kWave - 1)) * 4;
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)win0);
+            const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)win1);
+            win0 = (uint32_t)lane + adv < (uint32_t)kWave ? s0 : s1;
+            const uint32_t t1 = cursor + (uint32_t)kWave + (uint32_t)lane;
+            win1 = t1 < count ? tok[t1] : 0u;
+        }
         if (q.error != 0) { err = q.error; }
         if (lit.fault | pos.fault) { err = kE2BIG; }
     }
