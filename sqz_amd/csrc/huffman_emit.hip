@@ -8,13 +8,16 @@
 //   squeeze.h:239-246 squeeze_write_huffman    (code from the tree BEFORE the
 //                                               frequency update)
 //   squeeze.h:248-253 squeeze_flush, bitstream.h:28-63 (MSB-first words)
-// The wave runs uniformly: tokens are staged 128 at a time into LDS by all
-// lanes; per symbol lane k takes level k of the leaf->root chain, so the
-// Huffman code is one __ballot ("am I the hi child?") and the frequency update
-// is the parallel fast path of sqz_device.h (slow path on lane 0 when the tree
-// restructures).  Codes and raw bit fields are queued as (value, width) pairs;
-// every ~60 fields the wave packs them in parallel (prefix sum of the widths,
-// LDS atomic OR into a bit image) and stores whole 8-byte words, coalesced.
+// The wave runs uniformly.  Up to 64 tokens per step, one per lane: every lane walks the
+// leaf->root chains of its token's symbols, reads the code off the chain and takes part in the
+// batched frequency update of sqz_device.h (bump_lanes); the tokens in front of the first lane
+// whose update could restructure a tree are applied and their bits -- code, extra bits, code,
+// extra bits, concatenated per lane -- are packed in parallel (prefix sum of the widths, LDS
+// atomic OR into a bit image) and leave as whole 8-byte words, coalesced.  The token a step
+// stops at (a restructure, an unseen symbol with its NYT escape) takes the one-at-a-time path:
+// lane k = level k of the chain, code = one __ballot("am I the hi child?"), the reference's
+// own swap / promote tests, restructuring on the whole wave; its fields are queued as
+// (value, width) pairs and packed with the next batch.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
@@ -190,10 +193,10 @@ __device__ __forceinline__ bool token_ok(uint32_t t) {
 }
 
 // Tokens of stage 1 -> bit stream.  Up to 64 tokens per step, one per lane
-// (sqz_device.h: bump_lanes); a step shrinks to the tokens in front of the first
-// unseen symbol, halves when the no-restructure tests fail, and a single token that
-// still fails (= the tree really restructures) or needs the NYT escape goes through the
-// one-at-a-time path.
+// (sqz_device.h: bump_lanes); a step shrinks to the tokens in front of the first unseen or
+// malformed one, then to the longest prefix that changes no link, and the token it stops at
+// (the tree really restructures, or it needs the NYT escape) goes through the one-at-a-time
+// path in the same step.
 __global__ __launch_bounds__(kWave)
 void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                          const uint64_t* __restrict__ tok_off,

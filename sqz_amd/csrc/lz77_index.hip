@@ -10,19 +10,24 @@
 // nearest-first with strict >"), validated like bst.c:254-308 validates its
 // finder: token-for-token equality with the brute-force scan (tests).
 //
-// Three kernels, all data parallel except the last:
+// Three kernels:
 //   index_sort_kernel   one 1024-thread workgroup per stream: stable LSD radix
 //                       sort (3 passes x 8 bits) of the positions 0..n-3 by their
-//                       3-byte prefix.  Equal prefixes end up adjacent, positions
-//                       ascending inside a run.
+//                       3-byte prefix; the three histograms come from one sweep over
+//                       the bytes, every pass orders 4096-element tiles in LDS so that
+//                       a digit's elements leave as contiguous runs.  Equal prefixes
+//                       end up adjacent, positions ascending inside a run.
 //   index_match_kernel  one thread per position (all positions, not only token
 //                       starts -- there is no serial dependence here): walk the
 //                       run backwards = nearest first, stop at distance
 //                       min(i, window-1), keep the first strictly longer match,
-//                       stop at len == min(bytes-i, 257).  -> match[i]
+//                       stop at len == min(bytes-i, 257).  -> match[i].  A wave whose
+//                       64 ranks lie inside one run walks the candidates once for
+//                       all its lanes; a stream's workgroups share one XCD.
 //   index_parse_kernel  one wavefront per stream: the greedy step
 //                       (squeeze.h:377-394) over match[] -> the token words of
-//                       stage 1 (same format as lz77_scan.hip).
+//                       stage 1 (same format as lz77_scan.hip), found by per-chunk
+//                       walks that merge with the real path instead of one serial walk.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 

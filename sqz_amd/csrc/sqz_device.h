@@ -4,25 +4,29 @@
 // Reference semantics restated here (file:line relative to
 // /root/reference/attic/map_experiment):
 //   huffman.h:13-34   node / tree          -> Tree<> (LDS resident, compact ids)
-//   huffman.h:41-62   huffman_update_paths -> Tree::relabel
-//   huffman.h:64-86   huffman_swap_siblings-> Tree::order_pair
+//   huffman.h:41-62   huffman_update_paths -> Tree::relabel (one lane), relabel_moved / relabel_wave
+//   huffman.h:64-86   huffman_swap_siblings-> Tree::order_pair, order_only
 //   huffman.h:90-96   huffman_update_freq  -> Tree::sum
-//   huffman.h:98-147  move_up / frequency_changed -> Tree::changed
-//   huffman.h:149-216 huffman_insert       -> Tree::insert
-//   huffman.h:218-235 huffman_inc_frequency-> Tree::bump
+//   huffman.h:98-147  move_up / frequency_changed -> Tree::changed (one lane), changed_all (whole wave)
+//   huffman.h:149-216 huffman_insert       -> Tree::insert_splice + changed_all
+//   huffman.h:218-235 huffman_inc_frequency-> Tree::bump_wave (one symbol), bump_lanes (up to 64 tokens)
 //   squeeze.h:29-79,151-172 DEFLATE tables -> len_code()/pos_code() arithmetic
 //   bitstream.h:28-63,112-114 bit packer   -> BitQueue (huffman_emit.hip)
 //   bitstream.h:65-103 bit reader          -> BitSource
 //
 // Layout decisions:
-//  * one wavefront owns one stream; the two trees live in LDS; the serial
-//    update chain runs on lane 0, the other lanes help with bulk data moves.
+//  * one wavefront owns one stream; both trees live in LDS.  Most updates change no link and
+//    are applied up to 64 tokens at a time with one lane per token (bump_lanes); a token whose
+//    update restructures a tree takes the exact path, where lane k holds level k of the
+//    symbol's leaf->root chain and the restructuring itself (climb, promotions, relabel) is
+//    spread over the wave.  Only the splice of a new leaf and trees deeper than 56 levels run
+//    the reference sequence on a single lane.
 //  * node ids are compacted: leaves keep their symbol value, internal nodes
 //    are numbered upwards from LEAVES (root == LEAVES).  The reference numbers
 //    internals downwards from 2n-2; no emitted bit depends on the numbering.
-//  * a node stores its code in STREAM order (first branch = most significant
-//    bit) instead of the reference's LSB-first `path`; the bit packer then
-//    appends codes without reversing them.  Same bits on the wire.
+//  * no code is stored: a symbol's code is the "am I the hi child" bits along its chain, read
+//    in STREAM order (first branch = most significant bit), so the bit packer appends codes
+//    without reversing them.  Same bits on the wire as the reference's LSB-first `path`.
 #pragma once
 
 #include <hip/hip_runtime.h>
