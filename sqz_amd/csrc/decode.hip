@@ -301,7 +301,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             uint64_t starts = 0;
             uint32_t s = 0;
             do {
-                starts |= 1ull << s;
+                asm("s_bitset1_b64 %0, %1" : "+s"(starts) : "s"(s));      // starts |= 1 << s, one scalar op
                 s += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s);
             } while (s < (uint32_t)kWave);
             if (s >= 128u) {                                      // the last start is the refused one
