@@ -16,20 +16,18 @@
 // atomic OR into a bit image) and leave as whole 8-byte words, coalesced.  The token a step
 // stops at (a restructure, an unseen symbol with its NYT escape) takes the one-at-a-time path:
 // lane k = level k of the chain, code = one __ballot("am I the hi child?"), the reference's
-// own swap / promote tests, restructuring on the whole wave; its fields are queued as
-// (value, width) pairs and packed with the next batch.
+// own swap / promote tests, restructuring on the whole wave; its bits wait in a register and
+// ride along with the next batch's pack.
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
 namespace sqzk {
 
-constexpr int kQueue = 32;            // fields of the one-at-a-time path per pack
-constexpr int kQueueRoom = 8;         // a token adds at most 6 fields (+2 for a 63-bit code)
-constexpr int kImageWords = 62;       // 64 lanes x <= 58 bits + carry
+constexpr int kImageWords = 62;       // carry + pending + 64 lanes x <= 58 bits
+constexpr int kLaneBits = 58;         // most bits one lane (or the pending register) hands to a pack
 
 struct EmitLds {
     EntropyLds entropy;
-    uint64_t   field[kQueue];         // width << 32 | value   (width 1..32)
     uint64_t   image[kImageWords];    // packed bits of one batch, stream order = MSB first
 };
 
@@ -38,27 +36,13 @@ struct BitQueue {
     uint8_t* out;        // global
     uint64_t capacity;
     uint64_t bytes;      // bytes produced so far (as the reference counts them)
-    int      count;      // queued fields
     int      carry;      // bits already sitting in image[0] (0..63)
     int      error;
-
-    // value's low `width` bits, first-out bit = most significant; width 1..32
-    __device__ __forceinline__ void push32(uint32_t value, int width, int lane) {
-        if (lane == 0) { lds->field[count] = ((uint64_t)(uint32_t)width << 32) | (uint64_t)value; }
-        count++;
-    }
-    __device__ __forceinline__ void push(uint64_t value, int width, int lane) {
-        if (width > 32) {
-            push32((uint32_t)(value >> 32), width - 32, lane);
-            push32((uint32_t)value, 32, lane);
-        } else {
-            push32((uint32_t)value, width, lane);
-        }
-    }
-    // value LSB first (squeeze_write_bits, squeeze.h:231-237), width 1..32
-    __device__ __forceinline__ void push_lsb(uint32_t value, int width, int lane) {
-        push32(__brev(value) >> (32 - width), width, lane);
-    }
+    // bits of the one-at-a-time path waiting for the next pack: the low pend_n bits of pend_v,
+    // first-out bit on top.  They ride along with the next batch instead of costing a pack of
+    // their own (most steps end with one such token).
+    uint64_t pend_v;
+    int      pend_n;
 
     // store 8-byte words [0, words) of the image (bitstream.h:33-43)
     __device__ __forceinline__ void store_words(int words, int lane) {
@@ -79,27 +63,31 @@ struct BitQueue {
         else { bytes = capacity; error = kE2BIG; }
     }
 
-    // every lane contributes `n` bits (0..58, first-out bit = most significant of v):
-    // prefix sum of the widths, LDS atomic OR into the image behind the carried bits,
-    // full words leave for HBM
+    // n bits of v (first-out bit = most significant of the n) at stream bit o of the image
+    __device__ __forceinline__ void deposit(uint64_t v, uint32_t n, uint32_t o) {
+        const uint32_t w = o >> 6, s = o & 63u;
+        if (s + n <= 64) {
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+                     (unsigned long long)v << (64 - s - n));
+        } else {
+            const uint32_t r = s + n - 64;              // bits spilling into the next word
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+                     (unsigned long long)(v >> r));
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w + 1]),
+                     (unsigned long long)v << (64 - r));
+        }
+    }
+
+    // the pending bits, then every lane's `n` bits (0..58, first-out bit = most significant of
+    // v): prefix sum of the widths, LDS atomic OR into the image behind the carried bits, full
+    // words leave for HBM
     __device__ __forceinline__ void pack_lanes(uint64_t v, uint32_t n, int lane) {
         uint32_t incl = n;
         incl = wave_scan(incl);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + (uint32_t)carry;
-        if (n != 0) {
-            const uint32_t o = (uint32_t)carry + incl - n;  // first stream bit of this lane's bits
-            const uint32_t w = o >> 6, s = o & 63u;
-            if (s + n <= 64) {
-                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
-                         (unsigned long long)v << (64 - s - n));
-            } else {
-                const uint32_t r = s + n - 64;              // bits spilling into the next word
-                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
-                         (unsigned long long)(v >> r));
-                atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w + 1]),
-                         (unsigned long long)v << (64 - r));
-            }
-        }
+        const uint32_t head = (uint32_t)carry + (uint32_t)pend_n;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + head;
+        if (pend_n != 0 && lane == 0) { deposit(pend_v, (uint32_t)pend_n, (uint32_t)carry); }
+        if (n != 0) { deposit(v, n, head + incl - n); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const int words = (int)(total >> 6);
         store_words(words, lane);
@@ -107,19 +95,32 @@ struct BitQueue {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane < kImageWords) { lds->image[lane] = (lane == 0) ? rest : 0ull; }
         carry = (int)(total & 63u);
+        pend_v = 0; pend_n = 0;
     }
 
-    // the queued fields of the one-at-a-time path (lane j = field j)
+    // what is pending, alone (the register is full, or the stream ends)
     __device__ __forceinline__ void pack(int lane) {
-        if (count == 0) { return; }
-        uint32_t v = 0, n = 0;
-        if (lane < count) {
-            const uint64_t f = lds->field[lane];
-            v = (uint32_t)f;
-            n = (uint32_t)(f >> 32);
+        if (pend_n != 0) { pack_lanes(0ull, 0u, lane); }
+    }
+
+    // value's low `width` bits, first-out bit = most significant; width 1..32
+    __device__ __forceinline__ void push32(uint32_t value, int width, int lane) {
+        if (pend_n + width > kLaneBits) { pack(lane); }
+        const uint64_t bits = width >= 32 ? (uint64_t)value : (uint64_t)(value & ((1u << width) - 1u));
+        pend_v = (pend_v << width) | bits;
+        pend_n += width;
+    }
+    __device__ __forceinline__ void push(uint64_t value, int width, int lane) {
+        if (width > 32) {
+            push32((uint32_t)(value >> 32), width - 32, lane);
+            push32((uint32_t)value, 32, lane);
+        } else {
+            push32((uint32_t)value, width, lane);
         }
-        pack_lanes((uint64_t)v, n, lane);
-        count = 0;
+    }
+    // value LSB first (squeeze_write_bits, squeeze.h:231-237), width 1..32
+    __device__ __forceinline__ void push_lsb(uint32_t value, int width, int lane) {
+        push32(__brev(value) >> (32 - width), width, lane);
     }
 
     __device__ __forceinline__ void flush(int lane) {       // bitstream.h:112-114
@@ -128,7 +129,6 @@ struct BitQueue {
     }
 };
 
-// code of a leaf deeper than the wave is wide (never seen in practice): serial walk
 __device__ __noinline__ uint64_t deep_code(const uint64_t* link, int leaf, int& width) {
     uint64_t code = 0;
     int n = 0, a = leaf;
@@ -233,7 +233,8 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     q.out = out + o0;
     q.capacity = o1 - o0;
     q.bytes = 0;
-    q.count = 0;
+    q.pend_v = 0;
+    q.pend_n = 0;
     q.carry = prefix_fill;
     q.error = 0;
     int err = 0;
@@ -313,8 +314,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             }
             if (lane >= m) { n = 0; v = 0; }
             if (__ballot(n > 58) != 0) { err = kE2BIG; }               // codes this long never occur
-            q.pack(lane);                                              // fields still queued go first
-            q.pack_lanes(v, n, lane);
+            q.pack_lanes(v, n, lane);                                  // what the last one-at-a-time token left goes first
             cursor += (uint32_t)m;
         }
         ES(2)
@@ -324,7 +324,6 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)traw, m);
             if (!token_ok(tx)) { err = kEINVAL; break; }
             emit_token(q, lit, pos, tx, lane, err);
-            if (q.count > kQueue - 2 * kQueueRoom) { q.pack(lane); }
             cursor += 1;
 #ifdef SQZ_STATS
             es_exact++;
