@@ -929,51 +929,54 @@ __device__ unsigned long long g_st[8];
 #endif
 struct LaneWalk {
     int base;
+    uint32_t root;       // the tree's root (relative to base): an index that is always safe to follow
     uint32_t c;          // node whose counter comes next
     uint64_t w;          // its word
     bool live, bad, prev_hi;
     uint32_t prev_reach;
-    int k;
-    uint32_t code;       // hi/lo choices, leaf level first (walks deeper than 30 go to the serial path)
+    int depth;           // of the leaf (0 when there is none)
+    uint32_t code;       // hi/lo choices, leaf level first
 
     __device__ __forceinline__ void open(const uint64_t* link, int leaf) {
-        live = leaf >= 0; bad = false; prev_hi = false; prev_reach = 0; k = 0; code = 0;
+        live = leaf >= 0; prev_hi = false; prev_reach = 0; code = 0;
         base = leaf >= kLitNodes ? kLitNodes : 0;
-        c = live ? (uint32_t)(leaf - base) : 0u;
+        root = leaf >= kLitNodes ? (uint32_t)kPosLeaves : (uint32_t)kLitLeaves;
+        c = live ? (uint32_t)(leaf - base) : root;
         w = link[base + (int)c];
+        depth = live ? (int)((uint32_t)(w >> 52) & 0x3Fu) : 0;
+        bad = depth >= 29;                                   // never: such a chain is left to the serial path
     }
 
     // the tests at one level: `node` (counter value before my add: `old`) under a parent
-    // whose children are `kids`.  Two properties of the tree at rest keep this short (the
-    // oracle asserts both after every update, `make -C oracle check-invariants`): a chain node
-    // of a seen symbol always has a sibling, and lo <= hi for every pair -- so a hi child needs
-    // no test against its own sibling (the reference's swap can only be triggered from the lo
-    // side), only against its uncle, which is the next level's sibling.
+    // whose children are `kids`; `at` = how many levels above the leaf.  Two properties of the
+    // tree at rest keep this short (the oracle asserts both after every update,
+    // `make -C oracle check-invariants`): a chain node of a seen symbol always has a sibling,
+    // and lo <= hi for every pair -- so a hi child needs no test against its own sibling (the
+    // reference's swap can only be triggered from the lo side), only against its uncle, which
+    // is the next level's sibling.  Levels past the end of a chain look at the root's children
+    // instead (always two of them while any symbol is seen), so no index needs a guard.
     template <bool kWantCode>
     __device__ __forceinline__ void level(const uint32_t* freq, uint32_t node, uint32_t old, uint32_t kids,
-                                          bool valid) {
+                                          bool valid, int at) {
         const uint32_t lo = kids & 0x3FFu, hi = (kids >> 10) & 0x3FFu;
         const bool is_hi = (hi == node);
         const uint32_t sib = is_hi ? lo : hi;
-        const uint32_t f0s = freq[base + (int)(sib != kNil ? sib : node)] & kCountMask;
+        const uint32_t f0s = freq[base + (int)sib] & kCountMask;
         const uint32_t reach = (old & kCountMask) + (old >> kCntShift) + 1u;   // my count of the node after my add
         bad |= valid & !is_hi & (reach > f0s);                           // a lo child overtaking its sibling
         bad |= valid & prev_hi & (prev_reach > f0s);                     // the hi child below overtaking its uncle
-        if (kWantCode) {
-            code |= ((valid & is_hi) ? 1u : 0u) << k;
-            k += valid ? 1 : 0;
-        }
+        if (kWantCode) { code |= ((valid & is_hi) ? 1u : 0u) << at; }
         prev_hi = is_hi;             // past the end of a chain these are never looked at again:
         prev_reach = reach;          // every later level is invalid too and masks its tests
     }
 
     // sweep 1: count + test (+ code: the encoder emits it, the decoder has no use for it),
-    // three levels
+    // levels at, at + 1, at + 2 above the leaf
     template <bool kWantCode>
-    __device__ __forceinline__ void count3(const uint64_t* link, uint32_t* freq) {
+    __device__ __forceinline__ void count3(const uint64_t* link, uint32_t* freq, int at) {
         const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
         const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
-        const uint32_t i1 = v1 ? p1 : c, i2 = v2 ? p2 : c, i3 = v3 ? p3 : c;
+        const uint32_t i1 = v1 ? p1 : root, i2 = v2 ? p2 : root, i3 = v3 ? p3 : root;
         const uint32_t kids1 = (uint32_t)(link[base + (int)i1] >> 32);
         const uint32_t kids2 = (uint32_t)(link[base + (int)i2] >> 32);
         const uint64_t w3 = link[base + (int)i3];
@@ -984,10 +987,9 @@ struct LaneWalk {
         if (v1) { old0 = atomicAdd(&freq[base + (int)c], kCntOne); }
         if (v2) { old1 = atomicAdd(&freq[base + (int)i1], kCntOne); }
         if (v3) { old2 = atomicAdd(&freq[base + (int)i2], kCntOne); }
-        level<kWantCode>(freq, c, old0, kids1, v1);
-        level<kWantCode>(freq, p1, old1, kids2, v2);
-        level<kWantCode>(freq, p2, old2, (uint32_t)(w3 >> 32), v3);
-        if (kWantCode && k >= 29) { bad = true; }                        // never: left to the serial path
+        level<kWantCode>(freq, c, old0, kids1, v1, at);
+        level<kWantCode>(freq, p1, old1, kids2, v2, at + 1);
+        level<kWantCode>(freq, p2, old2, (uint32_t)(w3 >> 32), v3, at + 2);
         live = v3; c = i3; w = w3;
     }
 
@@ -995,7 +997,7 @@ struct LaneWalk {
     __device__ __forceinline__ void add3(const uint64_t* link, uint32_t* freq, uint32_t delta) {
         const uint32_t p1 = (uint32_t)w & 0x3FFu, p2 = ((uint32_t)w >> 10) & 0x3FFu, p3 = ((uint32_t)w >> 20) & 0x3FFu;
         const bool v1 = live & (p1 != kNil), v2 = v1 & (p2 != kNil), v3 = v2 & (p3 != kNil);
-        const uint32_t i3 = v3 ? p3 : c;
+        const uint32_t i3 = v3 ? p3 : root;
         const uint64_t w3 = link[base + (int)i3];
         if (v1) { atomicAdd(&freq[base + (int)c], delta); }         // not the root (see count3)
         if (v2) { atomicAdd(&freq[base + (int)p1], delta); }
@@ -1020,21 +1022,17 @@ __device__ __forceinline__ int bump_lanes(uint64_t* link, uint32_t* freq, int la
 #endif
     wa.open(link, la);
     wb.open(link, lb);
-    if (!kWantCode) {                                                    // the walk does not count its levels: ask the leaf
-        wa.bad = wa.live && ((uint32_t)(wa.w >> 52) & 0x3Fu) >= 29u;
-        wb.bad = wb.live && ((uint32_t)(wb.w >> 52) & 0x3Fu) >= 29u;
-    }
     BL_SEC(0)
-    while (__ballot(wa.live | wb.live) != 0) {
-        wa.template count3<kWantCode>(link, freq);
-        if (__ballot(wb.live) != 0) { wb.template count3<kWantCode>(link, freq); }
+    for (int at = 0; __ballot(wa.live | wb.live) != 0; at += 3) {
+        wa.template count3<kWantCode>(link, freq, at);
+        if (__ballot(wb.live) != 0) { wb.template count3<kWantCode>(link, freq, at); }
 #ifdef SQZ_STATS
         if (blockIdx.x == 1 && threadIdx.x == 0) { g_st[4] += 1; }
 #endif
     }
     BL_SEC(1)
-    code_a = wa.code; depth_a = wa.k;
-    code_b = wb.code; depth_b = wb.k;
+    code_a = wa.code; depth_a = wa.depth;
+    code_b = wb.code; depth_b = wb.depth;
     const uint64_t bm = __ballot(wa.bad | wb.bad);
     const int ok = bm != 0 ? __builtin_ctzll(bm) : m;                    // tokens in front of the first bad lane
     const uint32_t delta = lane < ok ? (1u - kCntOne) : (0u - kCntOne);
