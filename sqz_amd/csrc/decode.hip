@@ -207,7 +207,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             }
         }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
-                            ntok > (1u << 24);
+                            ntok > (1u << 24) - 256u;
         if (lit.lut_ok == 0) { lit.build_lut(lane); }
         if (pos.lut_ok == 0) { pos.build_lut(lane); }
         // ---- read ahead with the trees held still: every lane decodes the token that would

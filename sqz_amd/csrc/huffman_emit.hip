@@ -294,7 +294,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         const uint64_t vmask = __ballot(valid);
         int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
-                            cursor > (1u << 24);
+                            cursor > (1u << 24) - 256u;
         uint64_t ca = 0, cb = 0;
         int wa = 0, wb = 0;
         const int offered = m;

@@ -905,7 +905,7 @@ struct EntropyLds {
 // may be conservative -- the token a step stops at goes through the one-at-a-time
 // path -- but the output is always the reference's.
 //
-// n(c) is counted in the top 7 bits of the count word with LDS atomic adds whose return
+// n(c) is counted in the top byte of the count word with LDS atomic adds whose return
 // value tells a lane how many lanes were counted at c before it (its rank r).  A lane is
 // `bad` if, at some node of its chains, f0(c) + r + 1 would break one of the three tests.
 // Take the tokens in front of the first bad lane: for every node at most `allowed` of them
@@ -914,8 +914,9 @@ struct EntropyLds {
 // order can only shorten the prefix.  Two sweeps over the chains:
 //   1. count + test + read the code off the chain
 //   2. prefix lanes: count += 1, n -= 1; the others: n -= 1
-// Batching stops once a root count nears 2^25 (the serial path has no such limit).
-constexpr uint32_t kCntShift = 25;
+// Batching stops once a stream nears 2^24 tokens -- no count may outgrow its 24 bits -- (the
+// serial path has no such limit).
+constexpr uint32_t kCntShift = 24;
 constexpr uint32_t kCntOne = 1u << kCntShift;
 constexpr uint32_t kCountMask = kCntOne - 1u;
 
@@ -962,9 +963,9 @@ struct LaneWalk {
         const bool is_hi = (hi == node);
         const uint32_t sib = is_hi ? lo : hi;
         const uint32_t f0s = freq[base + (int)sib] & kCountMask;
-        const uint32_t reach = (old & kCountMask) + (old >> kCntShift) + 1u;   // my count of the node after my add
-        bad |= valid & !is_hi & (reach > f0s);                           // a lo child overtaking its sibling
-        bad |= valid & prev_hi & (prev_reach > f0s);                     // the hi child below overtaking its uncle
+        const uint32_t reach = (old & kCountMask) + (old >> kCntShift);  // the node's count BEFORE my add
+        bad |= valid & !is_hi & (reach >= f0s);                          // a lo child overtaking its sibling (reach + 1 > f0s)
+        bad |= valid & prev_hi & (prev_reach >= f0s);                    // the hi child below overtaking its uncle
         if (kWantCode) { code |= ((valid & is_hi) ? 1u : 0u) << at; }
         prev_hi = is_hi;             // past the end of a chain these are never looked at again:
         prev_reach = reach;          // every later level is invalid too and masks its tests
