@@ -358,7 +358,7 @@ void index_match_kernel(const uint8_t* __restrict__ in,
 // where the previous chunk's path left -- only has to be followed until it steps on a
 // position the guess also visited; from there the guess is right.  That fix-up runs chunk
 // by chunk, a few hops each, instead of one hop per token.
-constexpr int kChunk = 32;                          // positions per lane
+constexpr int kChunk = 32;                          // positions per lane (<= 32: one mask bit each)
 constexpr int kTile = kChunk * kWave;               // positions per pass
 constexpr int kChunkRow = kChunk + 1;               // padded: same-offset reads of all lanes spread over the banks
 
@@ -419,36 +419,35 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
         const uint32_t lo = (uint32_t)lane * (uint32_t)kChunk;
         const uint32_t room = have > lo ? (have - lo < (uint32_t)kChunk ? have - lo : (uint32_t)kChunk) : 0u;
         const uint32_t* row = &lds.m[lane * kChunkRow];
-        uint64_t guess = 0;
+        uint32_t guess = 0;                          // one bit per position of the chunk (kChunk <= 32)
         uint32_t p = 0;
         while (p < room) {
-            guess |= 1ull << p;
+            guess |= 1u << p;
             const uint32_t w = row[p];
             p += parse_step(w);
         }
         const uint32_t guess_out = lo + p;           // where the guess leaves the chunk (>= lo + room)
 
         // ---- the real path, chunk by chunk (uniform) -----------------------------------
-        uint64_t mine = 0;                           // this lane's chunk: real token starts
+        uint32_t mine = 0;                           // this lane's chunk: real token starts
         uint32_t e = entry;
         for (int l = 0; l < kWave; l++) {
             const uint32_t clo = (uint32_t)l * (uint32_t)kChunk;
             if (clo >= have) { break; }
             const uint32_t chi = clo + (uint32_t)kChunk < have ? clo + (uint32_t)kChunk : have;
             if (e >= chi) { continue; }              // the path jumps over this chunk
-            const uint64_t g = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(guess >> 32), l) << 32) |
-                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)guess, l);
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)guess, l);
             const uint32_t gout = (uint32_t)__builtin_amdgcn_readlane((int)guess_out, l);
-            uint64_t real = 0;
+            uint32_t real = 0;
             uint32_t q = e - clo;
             const uint32_t croom = chi - clo;
             for (;;) {
-                if ((g >> q) & 1ull) {               // the guess was here too: the rest is the guess's
-                    real |= g & ~((1ull << q) - 1ull);
+                if ((g >> q) & 1u) {                 // the guess was here too: the rest is the guess's
+                    real |= g & ~((1u << q) - 1u);
                     e = gout;
                     break;
                 }
-                real |= 1ull << q;
+                real |= 1u << q;
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.m[l * kChunkRow + (int)q]);
                 q += parse_step(w);
                 if (q >= croom) { e = clo + q; break; }
@@ -458,13 +457,13 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
         entry = e - (uint32_t)kTile;                 // e >= have here; carried into the next tile
 
         // ---- token words, in order ----------------------------------------------------
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(mine);
+        const uint32_t cnt = (uint32_t)__builtin_popcount(mine);
         const uint32_t incl = wave_scan(cnt);
         uint32_t at = ntok + incl - cnt;
-        uint64_t bits = mine;
+        uint32_t bits = mine;
         while (bits != 0) {
-            const uint32_t k = (uint32_t)__builtin_ctzll(bits);
-            bits &= bits - 1ull;
+            const uint32_t k = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
             const uint32_t w = row[k];
             tok[at++] = w != 0 ? (kTokMatch | w) : (uint32_t)lds.d[lo + k];
         }
