@@ -33,6 +33,7 @@
 
 namespace sqzk {
 
+constexpr int kSharedGiveUp = 8;         // index_match: lanes gone their own way before a wave stops sharing its walk
 constexpr int kXcds = 8;                 // MI355X: 8 XCDs, workgroups dispatched round-robin over them
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
@@ -265,6 +266,30 @@ void index_match_kernel(const uint8_t* __restrict__ in,
         const uint32_t key = (i + 4 <= n) ? (load_u32_unaligned(src + i) & 0x00FFFFFFu)
             : ((uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16));
         uint32_t best = 0, dist = 0;
+        // one lane on its own: the candidates of ranks q_from-1, q_from-2, ... (nearest first)
+        auto walk = [&](uint32_t q_from) {
+            for (uint32_t q = q_from; q > 0 && best < cap; ) {
+                q--;
+                const uint32_t p = S[q];                       // p < i inside a run
+                if (i - p > reach) { break; }                  // everything further is farther
+                const uint32_t pk = load_u32_unaligned(src + p) & 0x00FFFFFFu;   // p < i: p+4 <= n
+                if (pk != key) { break; }                      // left the run
+                if (best >= (uint32_t)kLenMin && src[p + best] != src[i + best]) { continue; }
+                uint32_t k = 3;
+                while (k < cap) {
+                    if (i + k + 4 <= n) {
+                        const uint32_t x = load_u32_unaligned(src + p + k) ^ load_u32_unaligned(src + i + k);
+                        if (x != 0) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                        k += 4;
+                    } else {
+                        if (src[p + k] != src[i + k]) { break; }
+                        k++;
+                    }
+                }
+                if (k > cap) { k = cap; }
+                if (k > best) { best = k; dist = i - p; }      // strictly longer: nearest among equals
+            }
+        };
         const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
         if (__ballot(valid && key == key0 && i + 16 <= n) == ~0ull) {
             // ---- the whole wave sits inside one run of equal keys (a frequent 3-byte string) ---
@@ -274,7 +299,8 @@ void index_match_kernel(const uint8_t* __restrict__ in,
             // registers -- no per-lane gathers.  Same order (nearest first), same strict >.
             const uint32_t own0 = load_u32_unaligned(src + i), own1 = load_u32_unaligned(src + i + 4);
             const uint32_t own2 = load_u32_unaligned(src + i + 8), own3 = load_u32_unaligned(src + i + 12);
-            bool done = false;
+            bool done = false, deferred = false;
+            uint32_t resume = 0;
             uint32_t page_base = r0, page = i;               // page = sorted positions of ranks [page_base, +64)
             for (int64_t c = (int64_t)r0 + kWave - 2; c >= 0; c--) {
                 if (c < (int64_t)page_base) {
@@ -300,51 +326,34 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                              : x2 != 0 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
                              : x3 != 0 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
                 const bool want = below && !done;
-                if (want && len == 16u && cap > 16u) {       // longer than the registers hold
-                    uint32_t k = 16;
-                    while (k < cap) {
-                        if (i + k + 4 <= n) {
-                            const uint32_t x = load_u32_unaligned(cp + k) ^ load_u32_unaligned(src + i + k);
-                            if (x != 0) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                            k += 4;
-                        } else {
-                            if (cp[k] != src[i + k]) { break; }
-                            k++;
-                        }
+                if (want && len == 16u && cap > 16u) {       // longer than the registers hold:
+                    deferred = true;                         // this lane goes on by itself from here
+                    resume = (uint32_t)c + 1u;               // (a long compare inside this loop would
+                    done = true;                             // hold up the other 63 lanes)
+                } else {
+                    if (len > cap) { len = cap; }
+                    if (want && len > best) {                // strictly longer: nearest among equals
+                        best = len; dist = d;
+                        if (best >= cap) { done = true; }
                     }
-                    len = k;
                 }
-                if (len > cap) { len = cap; }
-                if (want && len > best) {                    // strictly longer: nearest among equals
-                    best = len; dist = d;
-                    if (best >= cap) { done = true; }
+                // a run of long matches (padding, repeated records): nearly every lane ends up on
+                // its own anyway, so stop sharing early instead of trickling them out one per turn
+                if (__builtin_popcountll(__ballot(deferred)) >= kSharedGiveUp) {
+                    if (!done) {
+                        deferred = true;
+                        resume = below ? (uint32_t)c : r;    // ranks [c, r) are behind me / nothing is
+                        done = true;
+                    }
+                    break;
                 }
             }
+            if (deferred) { walk(resume); }
             M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
             continue;
         }
         if (!valid) { continue; }
-        for (uint32_t q = r; q > 0 && best < cap; ) {
-            q--;
-            const uint32_t p = S[q];                       // p < i inside a run
-            if (i - p > reach) { break; }                  // everything further is farther
-            const uint32_t pk = load_u32_unaligned(src + p) & 0x00FFFFFFu;   // p < i: p+4 <= n
-            if (pk != key) { break; }                      // left the run
-            if (best >= (uint32_t)kLenMin && src[p + best] != src[i + best]) { continue; }
-            uint32_t k = 3;
-            while (k < cap) {
-                if (i + k + 4 <= n) {
-                    const uint32_t x = load_u32_unaligned(src + p + k) ^ load_u32_unaligned(src + i + k);
-                    if (x != 0) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                    k += 4;
-                } else {
-                    if (src[p + k] != src[i + k]) { break; }
-                    k++;
-                }
-            }
-            if (k > cap) { k = cap; }
-            if (k > best) { best = k; dist = i - p; }      // strictly longer: nearest among equals
-        }
+        walk(r);
         M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
     }
 }
