@@ -4,13 +4,22 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one encode pass (LZ77 scan + adaptive-Huffman emit) of the hot path
-over one batch of synthetic input that is already resident in HBM:
-BASELINE.json configs[2] = 4096 x 256 KB Zipf(s=1) blocks, window 32 KB, one
-independent stream per block.  With N ranks every rank owns its own 4096-block
-batch (global block ids rank*4096 ...), no data-path collective: weak scaling.
-`value` = uncompressed MB (10^6 B) encoded per second by all ranks.  The decode
-pass over the produced streams is timed right after, with the same K and W, and
+A "step" is one encode pass (LZ77 match finding + greedy parse + adaptive-Huffman emit) of
+the hot path over one batch of synthetic input that is already resident in HBM.
+
+  N = 1   BASELINE.json configs[2]: 4096 x 256 KB Zipf(s=1) blocks, window 32 KB, one
+          independent stream per block.
+  N > 1   BASELINE.json configs[3]: THE SAME 4096-block batch (global block ids 0..4095),
+          rank r owning the contiguous range shard.block_range(4096, r, N) -- 512 blocks per
+          GPU at N = 8.  Strong scaling: total work is fixed, `value` = the batch's
+          uncompressed MB (10^6 B) / the slowest rank's time.  Blocks are self-contained
+          streams, so the timed data path has no collective.  `with_transfer` repeats the
+          measurement with the batch starting and ending on rank 0: RCCL scatter of the
+          input ranges, encode, pack, gather of sizes + dense streams back in block order
+          (SURVEY.md section 8d config 4 asks for both figures).
+  --scaling weak  keeps the round-1 measurement (every rank its own --blocks batch).
+
+The decode pass over the produced streams is timed right after, with the same K and W, and
 reported in the same line (`decode_MBps`), together with
   roofline      the dominant kernel of the encode step (longest average launch, HIP
                 events on the launch stream, measured live in this process) vs the HBM roof
@@ -19,6 +28,7 @@ reported in the same line (`decode_MBps`), together with
                 single-thread on a bounded sample of the same workload (rank 0, N=1)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -62,14 +72,48 @@ def cpu_baseline(n_sample_blocks, block_bytes, win_bits):
                       f"of {os.cpu_count()}"}
 
 
+def kernel_build_id():
+    """identifies the kernels a traffic figure was measured on: sha256 of the device sources"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "sqz_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the last committed PMC run (profiles/traffic.json,
+    written by tools/profile_round.sh) -- but only if it was measured on THESE kernels."""
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tp):
+        return None, "no profiles/traffic.json"
+    with open(tp) as fh:
+        t = json.load(fh)
+    cur = t.get("current", {})
+    if cur.get("kernel_build_id") != kernel_build_id():
+        return None, (f"profiles/traffic.json was measured on build {cur.get('kernel_build_id')}, "
+                      f"this is {kernel_build_id()}: not reported")
+    k = cur.get("kernels", {}).get(kernel)
+    if not k:
+        return None, "kernel not in profiles/traffic.json"
+    return int(k["hbm_bytes_per_launch"]), cur.get("method")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=4096,
+                    help="blocks of the batch (strong: in total, shared by all ranks; weak: per GPU)")
     ap.add_argument("--block-bytes", type=int, default=262144)
     ap.add_argument("--win-bits", type=int, default=15)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = the same --blocks batch sharded over the ranks (configs[3]); "
+                         "weak = every rank its own --blocks batch")
+    ap.add_argument("--no-transfer", action="store_true",
+                    help="N>1, strong: skip the scatter/gather-inclusive measurement")
     ap.add_argument("--cpu-blocks", type=int, default=8, help="CPU baseline sample: blocks 0..7 (SURVEY.md 8d), about 26 s of one host core (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--finder", choices=["index", "scan"], default="index",
@@ -90,6 +134,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SQZ_BENCH_BACKEND", "nccl")      # nccl == RCCL on ROCm
@@ -97,20 +142,25 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    # collectives run on device tensors over RCCL; a gloo rehearsal stages them through the host
+    comm_dev = dev if backend in ("none", "nccl") else torch.device("cpu")
 
-    n, bb, wb = args.blocks, args.block_bytes, args.win_bits
+    bb, wb = args.block_bytes, args.win_bits
+    strong = args.scaling == "strong"
+    total_blocks = args.blocks if strong else args.blocks * world
+    lo, hi = shard.block_range(total_blocks, rank, world) if strong \
+        else (rank * args.blocks, (rank + 1) * args.blocks)
+    n = hi - lo                                    # blocks this rank owns
     info = sqz_amd.device_info()
     batch.set_finder(args.finder)
 
     # ---- synthetic input, generated straight into HBM ------------------------
-    d_in = batch.zipf_blocks(n, bb, first_block=rank * n, device=dev)
+    d_in = batch.zipf_blocks(n, bb, first_block=lo, device=dev)
     in_off = batch.uniform_offsets(n, bb, device=dev)
     enc = batch.Encoder(n, n * bb, sqz_amd.bound(bb), device=dev)
     d_back = torch.empty_like(d_in)
     derr = torch.zeros(n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-
-    red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
@@ -138,7 +188,7 @@ def main():
     tim = batch.get_timing(reset=True)
     batch.set_timing(False)
     assert int(err.abs().sum()) == 0, "encode reported errors"
-    # ---- secondary bound: what the serial stages actually chew through.
+    # ---- secondary figures: what the serial stages actually chew through.
     # tok_count[n] is the head of the encode scratch (include/sqz/sqz.h); block 0's token
     # words follow at the 256-byte-aligned offset.  Not timed.
     tok_counts = enc.scratch[:4 * n].view(torch.int32)
@@ -167,40 +217,99 @@ def main():
     if not args.no_verify:
         assert torch.equal(d_back, d_in), "round trip differs"
 
+    # ---- N>1, strong: the same step with the batch starting and ending on rank 0 --------
+    xfer = None
+    if world > 1 and strong and not args.no_transfer:
+        root_in = batch.zipf_blocks(total_blocks, bb, first_block=0, device=dev) if rank == 0 else None
+        if root_in is not None and comm_dev.type == "cpu":
+            root_in = root_in.cpu()
+        dense_buf = torch.empty(n * (sqz_amd.bound(bb) // 8 * 8), dtype=torch.uint8, device=dev)
+        parts = {"scatter": 0.0, "encode": 0.0, "gather": 0.0}
+
+        def transfer_step(timed):
+            t_a = time.perf_counter()
+            mine, span = shard.scatter_blocks(root_in, total_blocks, bb, comm_dev)
+            mine = mine.to(dev)
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            o, o_off, o_bytes, e = enc.encode(mine, in_off, 1 << wb)
+            dense, d_off = batch.pack_blocks(o, o_off, o_bytes, dense=dense_buf)
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            res = shard.gather_dense(dense, o_bytes, total_blocks, comm_dev)
+            torch.cuda.synchronize()
+            t_d = time.perf_counter()
+            if timed:
+                parts["scatter"] += t_b - t_a
+                parts["encode"] += t_c - t_b
+                parts["gather"] += t_d - t_c
+            return res
+
+        for _ in range(args.warmup):
+            transfer_step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            root_dense, root_sizes, root_off = transfer_step(True)
+        barrier()
+        x_s = shard.max_over_ranks(time.perf_counter() - t0, comm_dev)
+        if rank == 0:
+            # what came back is the batch's streams in block order: rank 0's own range must
+            # equal what it encoded locally, and the sizes must add up to the job's total
+            own = root_dense[:int(root_off[n])].to(dev)
+            loc_dense, loc_off = batch.pack_blocks(out, out_off, out_bytes)
+            assert torch.equal(own, loc_dense[:own.numel()]), "gathered streams differ from the local encode"
+            xfer = {"encode_MBps": round(total_blocks * bb / x_s * args.steps / 1e6, 3),
+                    "ms_per_step": round(x_s / args.steps * 1e3, 3),
+                    "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
+                    "gathered_bytes": int(root_off[-1]),
+                    "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
+                            f"dense streams (point-to-point per peer) -> rank 0, backend {backend}"}
+
     if world > 1:
-        enc_s = shard.max_over_ranks(enc_s, red_dev)
-        dec_s = shard.max_over_ranks(dec_s, red_dev)
-        comp_total = shard.sum_over_ranks(float(comp_bytes), red_dev)
-        tokens_all = int(shard.sum_over_ranks(float(tokens_rank), red_dev))
+        enc_s = shard.max_over_ranks(enc_s, comm_dev)
+        dec_s = shard.max_over_ranks(dec_s, comm_dev)
+        comp_total = shard.sum_over_ranks(float(comp_bytes), comm_dev)
+        tokens_all = int(shard.sum_over_ranks(float(tokens_rank), comm_dev))
     else:
         comp_total = float(comp_bytes)
         tokens_all = tokens_rank
 
     if rank == 0:
-        in_total = float(world) * n * bb
+        in_total = float(total_blocks) * bb
         ms_per_step = enc_s / args.steps * 1e3
         enc_k = {k: v[0] / max(v[1], 1) for k, v in tim.items()}      # avg ms per launch
         dec_k = {k: v[0] / max(v[1], 1) for k, v in dtim.items()}
         dominant = max(enc_k, key=enc_k.get)
-        algo_bytes = n * bb + comp_bytes          # encode = n + c per block
+        algo_bytes = n * bb + comp_bytes          # encode = n + c per block, this rank's launch
         achieved = algo_bytes / (enc_k[dominant] * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            with open(tp) as fh:
-                traffic = json.load(fh).get(dominant + "_hbm_bytes_per_launch")
+        traffic, traffic_note = measured_traffic(dominant) if (world == 1 and n == 4096 and bb == 262144) \
+            else (None, "traffic is measured on the N=1 default workload only")
+        if world == 1:
+            scaling = "strong" if strong else "weak"
+            workload = (f"{n} x {bb} B Zipf(s=1) byte blocks, window 2^{wb}, one independent stream per "
+                        "block (BASELINE.json configs[2])")
+            par = "1 rank; the N>1 runs shard this same batch (strong scaling)"
+        elif strong:
+            scaling = "strong"
+            workload = (f"the same {total_blocks} x {bb} B Zipf(s=1) batch (block ids 0..{total_blocks - 1}), "
+                        f"window 2^{wb}, sharded {n} blocks per GPU (BASELINE.json configs[3])")
+            par = f"contiguous block ranges over {world} ranks, no data-path collective in `value`"
+        else:
+            scaling = "weak"
+            workload = f"{n} x {bb} B Zipf(s=1) byte blocks per GPU, window 2^{wb}"
+            par = f"every rank its own batch, {world} ranks, no data-path collective"
         line = {
             "metric": "encode MB/s + decode MB/s, 32KB window, batched blocks, 1/2/4/8 MI355X",
             "value": round(in_total / enc_s * args.steps / 1e6, 3),
             "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} x {bb} B Zipf(s=1) byte blocks per GPU, window 2^{wb}, "
-                                   "one independent stream per block (BASELINE.json configs[2])",
-                       "blocks_per_gpu": n, "block_bytes": bb, "win_bits": wb,
-                       "parallelism": f"blocks sharded over {world} rank(s), no data-path collective",
+            "config": {"workload": workload,
+                       "total_blocks": total_blocks, "blocks_per_gpu": n, "block_bytes": bb, "win_bits": wb,
+                       "parallelism": par,
                        "finder": "index" if args.finder != "scan" else "scan",
                        "device": info["name"]},
             "decode_MBps": round(in_total / dec_s * args.steps / 1e6, 3),
@@ -210,24 +319,33 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 7), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "encode_frac_of_hbm_roof": round(
                              algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 7)},
         }
+        if xfer is not None:
+            line["with_transfer"] = xfer
         serial_ms = sum(enc_k.get(k, 0.0) for k in ("index_parse_kernel", "huffman_emit_kernel"))
-        line["secondary"] = {
+        sec = {
             "note": "the path is a serial chain per stream, not HBM-bound: tokens through the "
-                    "adaptive-Huffman stage per second, and the candidate tests the reference's "
-                    "O(window) scan makes for the same tokens (block 0 x blocks; the indexed finder "
-                    "visits only equal-prefix candidates, --finder scan performs them all)",
+                    "adaptive-Huffman stage per second",
             "tokens_per_step": tokens_all,
             "tokens_per_s_encode": round(tokens_all / (ms_per_step * 1e-3), 1),
             "tokens_per_s_emit_kernel": round(tokens_rank / (enc_k["huffman_emit_kernel"] * 1e-3), 1),
             "tokens_per_s_entropy_decode_kernel": round(tokens_rank / (dec_k["entropy_decode_kernel"] * 1e-3), 1),
-            "scan_candidate_tests_per_step": cand0 * n * world,
-            "scan_candidate_tests_per_s": round(cand0 * n * world / (ms_per_step * 1e-3), 1),
             "serial_stage_ms": round(serial_ms, 3),
         }
+        # the candidate tests the reference's O(window) scan makes for the same tokens (block 0 of
+        # this rank x its blocks).  Only --finder scan PERFORMS them; the indexed finder visits the
+        # equal-prefix candidates only, so for it the figure is what it avoids, not a rate it achieves.
+        cand = cand0 * n * (world if strong else world)
+        if args.finder == "scan":
+            sec["scan_candidate_tests_per_step"] = cand
+            sec["scan_candidate_tests_per_s"] = round(cand / (ms_per_step * 1e-3), 1)
+        else:
+            sec["reference_scan_candidate_tests_per_step_not_performed"] = cand
+        line["secondary"] = sec
         if world == 1 and args.cpu_blocks > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_blocks, bb, wb)
         print(json.dumps(line), flush=True)

@@ -48,33 +48,54 @@ enum {
 };
 
 /* ------------------------------------------------------------------ */
-/* bit stream over caller memory.  Replaces `bitstream` of
- * attic/map_experiment/bitstream.h:7-18 in its memory mode (:34-43, :70-80).
- * The 8-byte callback mode (`stream/output/input`, :16-17) cannot cross to the
- * device; callers that need it replay `data[0..bytes)` through their callback.
+/* Bit stream: `bitstream` of attic/map_experiment/bitstream.h:7-18, same fields in the same
+ * order, so the reference's designated initialisers compile unchanged
+ * (attic/map_experiment/test.c:53,110):
  *
- * writer: { .data = buf, .capacity = sizeof buf }          -> .bytes produced
- * reader: { .data = buf, .bytes = n }  (H0, attic test.c:110)  or
- *         { .data = buf, .capacity = n } (H1, shl/README.md:47-48)           */
+ *   memory mode   { .data = buf, .capacity = sizeof buf }            writer -> .bytes produced
+ *                 { .data = buf, .bytes = n }                        reader (H0, test.c:110)
+ *                 { .data = buf, .capacity = n }                     reader (H1, shl/README.md:47-48)
+ *   callback mode { .stream = f, .output = write_file }              writer (bitstream.h:44-48)
+ *                 { .stream = f, .input  = read_file  }              reader (bitstream.h:81-85)
+ *
+ * Callback mode is served by the shim, since a device cannot call the host per word
+ * (SURVEY.md section 8b "Ownership"):
+ *   writer  the stream is produced on the device into a host buffer, then every 64-bit word
+ *           is handed over exactly as bitstream.h:45-47 does: bs->b64 = word, bs->error =
+ *           bs->output(bs), bs->bytes += 8 on success, stop at the first error.  Same calls,
+ *           same order, same values as the reference makes.
+ *   reader  words are pulled with bs->input(bs) (bs->b64 = the word, bitstream.h:83) into a host
+ *           buffer and decoded from there.  The reference pulls a word when its bit reader
+ *           runs dry; the device decodes a whole buffer at once, so the shim pulls ahead:
+ *           first what a stream of `bytes` bytes takes at a 1:1 ratio, then twice as much each
+ *           time the decoder runs dry (E2BIG).  At most twice the words the reference would
+ *           have consumed are pulled; a callback error only surfaces if the decoder needed
+ *           words beyond it.  bs->read / bs->bits / bs->b64 are left as the reference's
+ *           reader would leave them (read = words the DECODER consumed x 8).               */
 typedef struct bitstream {
+    void*    stream;   /* callback context (bitstream.h:8); exclusive with (data, capacity) */
     uint8_t* data;
     uint64_t capacity; /* data[capacity] */
     uint64_t bytes;    /* bytes written (writer) / available (reader) */
     uint64_t read;     /* bytes consumed by the reader */
     uint64_t b64;      /* bit shifting buffer (bitstream.h:13) */
     int32_t  bits;     /* bit count inside b64 (bitstream.h:14) */
-    int32_t  error;    /* sticky errno (bitstream.h:15) */
+    int32_t  error;    /* sticky errno (bitstream.h:15; errno_t is int) */
+    int (*output)(struct bitstream* bs); /* write b64 as 8 bytes (bitstream.h:16) */
+    int (*input)(struct bitstream* bs);  /* read b64 as 8 bytes  (bitstream.h:17) */
 } bitstream;
 
-/* codec state.  Caller-owned, single-use per stream like the reference's
- * (squeeze.h:333-334 inserts the NYT leaves at the start of every call).
- * The trees themselves live on the device for the duration of a call; the
- * struct carries the sticky error and the counters of the last call.        */
+/* codec state (squeeze_type, squeeze.h:81-92).  Caller-owned, single-use per stream like the
+ * reference's (squeeze.h:333-334 inserts the NYT leaves at the start of every call).  The
+ * trees themselves live on the device for the duration of a call; the struct carries what the
+ * reference's callers read afterwards: the sticky error (first member, as in the reference)
+ * and the bit stream of the last call (`s->bs->bytes`, attic test.c:84).                  */
 struct sqz {
     int32_t  error;       /* sticky errno: README.md:126-131, squeeze.h:82 */
     int32_t  device;      /* HIP device ordinal used by the last call, -1 = default */
     uint64_t tokens;      /* LZ77 tokens of the last sqz_compress */
-    uint64_t reserved[5];
+    struct bitstream* bs; /* squeeze.h:89: set by compress / decompress */
+    uint64_t reserved[4];
 };
 typedef struct sqz sqz_type; /* README.md:128 */
 
@@ -97,7 +118,8 @@ SQZ_API void sqz_read_header_h0(struct bitstream* bs, uint64_t* bytes, uint8_t* 
  * reference's uint16_t argument; max distance is window-1).  Continues the bit
  * stream wherever sqz_write_header* left it and zero-pads to a 64-bit boundary
  * (bitstream.h:112-114).  Result in s->error (mirrored to bs->error), output
- * size in bs->bytes.  E2BIG when bs->capacity is too small (bitstream.h:38). */
+ * size in bs->bytes.  E2BIG when bs->capacity is too small (bitstream.h:38).  In callback
+ * mode (bs->data == NULL, bs->output set) every word goes through bs->output.            */
 SQZ_API void sqz_compress(struct sqz* s, struct bitstream* bs,
                           const uint8_t* data, size_t bytes, uint32_t window);
 
@@ -128,7 +150,7 @@ SQZ_API extern squeeze_interface squeeze;
  * of 8 bytes.  Block b reads  in[in_off[b] .. in_off[b+1])  and writes at most
  * out_off[b+1]-out_off[b] bytes at out + out_off[b]; the size goes to
  * out_bytes[b], the errno to err[b].  Offsets arrays have n+1 entries.
- * out_off[b] must be a multiple of 8.                                       */
+ * out_off[b] must be a multiple of 8.  Only out[out_off[b] .. + out_bytes[b]) is written.     */
 
 /* worst-case compressed size of one block of `bytes` bytes (multiple of 8) */
 SQZ_API uint64_t sqz_bound(uint64_t bytes);
@@ -156,7 +178,11 @@ SQZ_API int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_
 /* Device-resident flavour: every pointer is a DEVICE pointer on the current
  * HIP device (hipMalloc / torch.cuda tensor storage), `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.
- * `scratch` must hold sqz_hip_encode_scratch_bytes(n, total_in_bytes).      */
+ * `scratch` must hold sqz_hip_encode_scratch_bytes(n, in_off[n]): the per-byte work arrays
+ * are addressed by the ABSOLUTE offsets in d_in_off (in_off[0] need not be 0).  The offsets
+ * live on the device, so a scratch that is too small cannot be told at the call: the kernels
+ * refuse every block whose in_off[b+1] lies beyond it -- err[b] = EINVAL, out_bytes[b] = 0,
+ * nothing written out of bounds -- and the other blocks are unaffected.                    */
 SQZ_API uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes);
 SQZ_API int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n,
                                   uint32_t window,
@@ -197,6 +223,17 @@ SQZ_API int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_i
                                    void* d_out, const uint64_t* d_out_off,
                                    uint64_t* d_out_bytes, int32_t* d_err,
                                    void* stream);
+
+/* Streams of a batch, back to back: stream b moves from d_slabs + d_slab_off[b] (where
+ * sqz_hip_encode_blocks left it) to d_dense + d_dense_off[b]; d_dense_off = exclusive prefix
+ * sum of d_bytes, every entry a multiple of 8 (n + 1 entries, computed by the caller on the device).  The dense image with
+ * d_dense_off as offsets is what sqz_hip_decode_blocks reads, and what the multi-GPU gather
+ * of SURVEY.md section 8e ships (110 MB per 512 blocks instead of 269 MB of slabs).
+ * avg_bytes sizes the launch (total / n is fine).  All device pointers, asynchronous.       */
+SQZ_API int sqz_hip_pack_blocks(const void* d_slabs, const uint64_t* d_slab_off,
+                                const uint64_t* d_bytes, uint32_t n,
+                                void* d_dense, const uint64_t* d_dense_off,
+                                uint64_t avg_bytes, void* stream);
 
 /* which finder sqz_compress / sqz_*encode_blocks use: 1 = indexed (default),
  * 0 = brute-force scan; also settable with SQZ_FINDER=scan|index.           */

@@ -12,7 +12,7 @@
  *
  * Exposed C ABI (used by tests/ and oracle/gen_golden.py only):
  *   sqz_ref_compress / sqz_ref_decompress / sqz_ref_available /
- *   sqz_ref_tree_run / sqz_ref_compress_file / sqz_ref_decompress_file
+ *   sqz_ref_tree_run / sqz_ref_compress_file / sqz_ref_decompress_file / sqz_ref_compress_stats
  */
 #include <stdbool.h>
 #include <stdint.h>
@@ -40,6 +40,26 @@ int64_t sqz_ref_compress(const uint8_t* data, uint64_t bytes, int win_bits,
     squeeze_type* s = squeeze.alloc(0);
     if (s == NULL) { return -(int64_t)ENOMEM; }
     squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << win_bits));
+    int64_t r = s->error != 0 ? -(int64_t)s->error : (int64_t)bs.bytes;
+    squeeze.free(s);
+    return r;
+}
+
+/* the reference's own counters after a compress (huffman.h:29-33 per tree; entropy
+ * huffman.h:237-249; the tree depth marks): what SQUEEZE_MAP_STATS would print from
+ * (squeeze.h:397-403).  out[0..5] = lit updates/swaps/moves, pos updates/swaps/moves;
+ * ent[0..1] = entropy lit/pos; depth[0..1].  returns bytes written or -errno */
+int64_t sqz_ref_compress_stats(const uint8_t* data, uint64_t bytes, int win_bits,
+                               uint8_t* out, uint64_t capacity, uint64_t counters[6],
+                               double ent[2], int32_t depth[2]) {
+    bitstream bs = { .data = out, .capacity = capacity };
+    squeeze_type* s = squeeze.alloc(0);
+    if (s == NULL) { return -(int64_t)ENOMEM; }
+    squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << win_bits));
+    counters[0] = s->lit.stats.updates; counters[1] = s->lit.stats.swaps; counters[2] = s->lit.stats.moves;
+    counters[3] = s->pos.stats.updates; counters[4] = s->pos.stats.swaps; counters[5] = s->pos.stats.moves;
+    ent[0] = huffman_entropy(&s->lit); ent[1] = huffman_entropy(&s->pos);
+    depth[0] = s->lit.depth; depth[1] = s->pos.depth;
     int64_t r = s->error != 0 ? -(int64_t)s->error : (int64_t)bs.bytes;
     squeeze.free(s);
     return r;

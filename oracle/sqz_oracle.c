@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------ */
 /* alphabet constants: squeeze.h:9-25                                  */
@@ -141,6 +142,9 @@ typedef struct {
     int32_t  lo[MAX_NODES];    /* lix */
     int32_t  hi[MAX_NODES];    /* rix */
     int32_t  n, next, depth, complete;
+    /* huffman.h:29-33 `stats`: update_paths calls (one per node visited, :42), sibling
+     * exchanges carried out (:76), promotions carried out (:111) */
+    uint64_t st_updates, st_swaps, st_moves;
     /* explicit stacks standing in for the reference's recursion */
     int32_t  walk[MAX_NODES];
     int32_t  pend_parent[2 * MAX_NODES];
@@ -153,6 +157,7 @@ static void tree_init(tree* t, int32_t n) { /* huffman.h:251-269 */
     t->next = m - 1;
     t->depth = 0;
     t->complete = 0;
+    t->st_updates = t->st_swaps = t->st_moves = 0;
     for (int32_t i = 0; i < m; i++) {
         t->freq[i] = 0; t->path[i] = 0; t->bits[i] = 0;
         t->up[i] = -1; t->lo[i] = -1; t->hi[i] = -1;
@@ -169,6 +174,7 @@ static void tree_relabel(tree* t, int32_t top) {
         const int32_t v = t->walk[--sp];
         const int32_t b = t->bits[v];
         const uint64_t p = t->path[v];
+        t->st_updates++;                            /* huffman.h:42 */
         if (b > t->depth) { t->depth = b; }
         const int32_t l = t->lo[v], r = t->hi[v];
         if (r != -1) {
@@ -191,6 +197,7 @@ static int32_t tree_order_pair(tree* t, int32_t i) {
     if (p < 0) { return i; } /* root: :68 */
     const int32_t l = t->lo[p], r = t->hi[p];
     if (l >= 0 && r >= 0 && t->freq[l] > t->freq[r]) {
+        t->st_swaps++;                              /* huffman.h:76 */
         t->lo[p] = r;
         t->hi[p] = l;
         tree_relabel(t, p);
@@ -233,6 +240,7 @@ static void tree_changed(tree* t, int32_t start) {
         const int par_is_left = (par == t->lo[g]);
         const int32_t uncle = par_is_left ? t->hi[g] : t->lo[g];
         if (!(t->freq[c] > t->freq[uncle])) { continue; }
+        t->st_moves++;                              /* huffman.h:111 */
         t->up[c] = g;
         if (par_is_left) { t->hi[g] = c; } else { t->lo[g] = c; }
         t->hi[par] = uncle;
@@ -459,9 +467,31 @@ static void put_header(bit_sink* w, uint64_t bytes, int win_bits) {
     }
 }
 
-int sqzo_encode(const uint8_t* data, uint64_t bytes, uint32_t window,
-                int header_win_bits, uint8_t* out, uint64_t capacity,
-                uint64_t* out_bytes) {
+/* huffman.h:237-249 */
+static double tree_entropy(const tree* t) {
+    double total = 0.0, e = 0.0;
+    for (int32_t i = 0; i < t->n; i++) { total += (double)t->freq[i]; }
+    for (int32_t i = 0; i < t->n; i++) {
+        if (t->freq[i] > 0) {
+            const double p = (double)t->freq[i] / total;
+            e += p * log2(p);
+        }
+    }
+    return -e;
+}
+
+static void stats_of(const codec* c, uint64_t li, uint64_t br, sqzo_stats* st) {
+    if (st == NULL) { return; }
+    st->lit_updates = c->lit.st_updates; st->lit_swaps = c->lit.st_swaps; st->lit_moves = c->lit.st_moves;
+    st->pos_updates = c->pos.st_updates; st->pos_swaps = c->pos.st_swaps; st->pos_moves = c->pos.st_moves;
+    st->literal_bytes = li; st->backref_bytes = br;
+    st->lit_entropy = tree_entropy(&c->lit); st->pos_entropy = tree_entropy(&c->pos);
+    st->lit_depth = c->lit.depth; st->pos_depth = c->pos.depth;
+}
+
+int sqzo_encode_stats(const uint8_t* data, uint64_t bytes, uint32_t window,
+                      int header_win_bits, uint8_t* out, uint64_t capacity,
+                      uint64_t* out_bytes, sqzo_stats* st) {
     *out_bytes = 0;
     if (!window_ok(window)) { return EINVAL; }
     bit_sink w = { out, capacity, 0, 0, 0, 0 };
@@ -474,7 +504,7 @@ int sqzo_encode(const uint8_t* data, uint64_t bytes, uint32_t window,
     /* squeeze.h:333-334 */
     if (!tree_insert(&c->lit, LIT_NYT)) { c->error = EINVAL; }
     if (!tree_insert(&c->pos, POS_NYT)) { c->error = EINVAL; }
-    uint64_t i = 0;
+    uint64_t i = 0, li = 0, br = 0;                /* squeeze.h:327-328 li_bytes / br_bytes */
     while (i < bytes && c->error == 0) { /* squeeze.h:337-395 */
         uint32_t len, dist;
         sqzo_match_at(data, bytes, i, window, &len, &dist);
@@ -482,9 +512,11 @@ int sqzo_encode(const uint8_t* data, uint64_t bytes, uint32_t window,
             put_len(c, &w, len);
             put_pos(c, &w, dist);
             i += len;
+            br += len;
         } else {
             put_lit(c, &w, data[i]);
             i++;
+            li++;
         }
     }
     if (c->error == 0) { /* squeeze.h:248-253 */
@@ -492,6 +524,52 @@ int sqzo_encode(const uint8_t* data, uint64_t bytes, uint32_t window,
         c->error = w.error;
     }
     const int r = c->error;
+    stats_of(c, li, br, st);
+    free(c);
+    *out_bytes = w.bytes;
+    return r;
+}
+
+int sqzo_encode(const uint8_t* data, uint64_t bytes, uint32_t window,
+                int header_win_bits, uint8_t* out, uint64_t capacity,
+                uint64_t* out_bytes) {
+    return sqzo_encode_stats(data, bytes, window, header_win_bits, out, capacity, out_bytes, NULL);
+}
+
+/* squeeze.h:377-394 + :278-315 driven by a caller-made token sequence (payload only): what
+ * stage 2 of the HIP path (sqz_hip_huffman_blocks) is held against when a test needs a
+ * symbol sequence no input text produces -- very deep trees, or a distance the decoder must
+ * refuse.  Lengths 3..258 and distances 1..32768 are encodable by the code tables
+ * (squeeze.h:29-79); nothing checks that the tokens describe a consistent text. */
+int sqzo_encode_tokens(const uint32_t* tokens, uint64_t count, uint8_t* out,
+                       uint64_t capacity, uint64_t* out_bytes, sqzo_stats* st) {
+    *out_bytes = 0;
+    bit_sink w = { out, capacity, 0, 0, 0, 0 };
+    codec* c = codec_new();
+    if (c == NULL) { return ENOMEM; }
+    if (!tree_insert(&c->lit, LIT_NYT)) { c->error = EINVAL; }
+    if (!tree_insert(&c->pos, POS_NYT)) { c->error = EINVAL; }
+    uint64_t li = 0, br = 0;
+    for (uint64_t k = 0; k < count && c->error == 0; k++) {
+        const uint32_t t = tokens[k];
+        if ((t & SQZO_TOKEN_MATCH) != 0) {
+            const uint32_t len = (t >> 16) & 0x1FFu, dist = t & 0xFFFFu;
+            if (len < LEN_MIN || len > 258 || dist < 1 || dist > 32768) { c->error = EINVAL; break; }
+            put_len(c, &w, len);
+            put_pos(c, &w, dist);
+            br += len;
+        } else {
+            if (t > 0xFFu) { c->error = EINVAL; break; }
+            put_lit(c, &w, (int32_t)t);
+            li++;
+        }
+    }
+    if (c->error == 0) {
+        sink_flush(&w);
+        c->error = w.error;
+    }
+    const int r = c->error;
+    stats_of(c, li, br, st);
     free(c);
     *out_bytes = w.bytes;
     return r;

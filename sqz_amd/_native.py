@@ -11,16 +11,20 @@ LIB_PATH = os.environ.get("SQZ_AMD_LIB") or os.path.join(_HERE, "lib", "libsqz_a
 
 
 class Bitstream(C.Structure):
-    """struct bitstream of include/sqz/sqz.h (bitstream.h:7-18, memory mode)."""
-    _fields_ = [("data", C.POINTER(C.c_uint8)), ("capacity", C.c_uint64),
-                ("bytes", C.c_uint64), ("read", C.c_uint64), ("b64", C.c_uint64),
-                ("bits", C.c_int32), ("error", C.c_int32)]
+    """struct bitstream of include/sqz/sqz.h (bitstream.h:7-18, fields in the reference's order)."""
+
+
+WORD_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(Bitstream))
+Bitstream._fields_ = [("stream", C.c_void_p), ("data", C.POINTER(C.c_uint8)),
+                      ("capacity", C.c_uint64), ("bytes", C.c_uint64), ("read", C.c_uint64),
+                      ("b64", C.c_uint64), ("bits", C.c_int32), ("error", C.c_int32),
+                      ("output", WORD_CALLBACK), ("input", WORD_CALLBACK)]
 
 
 class Sqz(C.Structure):
     """struct sqz / sqz_type of include/sqz/sqz.h."""
     _fields_ = [("error", C.c_int32), ("device", C.c_int32), ("tokens", C.c_uint64),
-                ("reserved", C.c_uint64 * 5)]
+                ("bs", C.POINTER(Bitstream)), ("reserved", C.c_uint64 * 4)]
 
 
 KERNEL_NAMES = ["lz77_scan_kernel", "huffman_emit_kernel", "entropy_decode_kernel",
@@ -75,6 +79,7 @@ PROTOTYPES = {
     "sqz_hip_lz77_blocks_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int, _vp,
                                          C.c_uint64, _vp]),
     "sqz_hip_huffman_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sqz_hip_pack_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
     "sqz_hip_set_finder": (None, [C.c_int]),
     "sqz_hip_get_finder": (C.c_int, []),
     "sqz_hip_set_timing": (None, [C.c_int]),

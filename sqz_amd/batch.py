@@ -78,6 +78,20 @@ class Encoder:
         return toks, counts
 
 
+def pack_blocks(slabs, slab_off, sizes, dense=None):
+    """streams back to back (sqz_hip_pack_blocks): returns (dense uint8, offsets int64[n+1]).
+    The pair (dense, offsets) is a valid input of decode_blocks."""
+    from .shard import dense_offsets
+    n = sizes.numel()
+    off = dense_offsets(sizes)
+    if dense is None:
+        dense = torch.empty(int(off[-1]), dtype=torch.uint8, device=slabs.device)
+    avg = max(slabs.numel() // max(n, 1) // 2, 1)
+    _raise(N.lib().sqz_hip_pack_blocks(_ptr(slabs), _ptr(slab_off), _ptr(sizes), n, _ptr(dense),
+                                       _ptr(off), avg, _stream()), "sqz_hip_pack_blocks")
+    return dense, off
+
+
 _decode_scratch = {}
 
 

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -44,7 +45,9 @@ struct Ctx {
     int  cus = 0;
     uint64_t lds = 0;
     // staging pool of the host-buffer flavour (grow-only, guarded by mu)
-    DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit, work_a, work_m;
+    DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit, work_a, work_m,
+           dense, dense_off;
+    std::vector<uint8_t> host_dense;   // landing area of the host flavour's one device-to-host copy
 };
 
 Ctx& ctx() { static Ctx c; return c; }
@@ -87,8 +90,21 @@ struct Timing {
     bool enabled = false;
     std::vector<TimedSpan> spans;
     sqz_hip_timing acc = {};
+    // fold finished spans into acc and release their events (caller holds mu)
+    void drain_locked() {
+        for (TimedSpan& s : spans) {
+            float ms = 0.0f;
+            if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                if (s.kind >= 0 && s.kind < SQZ_HIP_KERNELS) { acc.ms[s.kind] += ms; acc.launches[s.kind]++; }
+            }
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+        spans.clear();
+    }
 };
 Timing& timing() { static Timing t; return t; }
+constexpr size_t kMaxPendingSpans = 4096;       // a caller that never reads the timing must not grow it forever
 
 struct SpanGuard {
     hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on = false;
@@ -107,19 +123,30 @@ struct SpanGuard {
         Timing& t = timing();
         std::lock_guard<std::mutex> g(t.mu);
         t.spans.push_back({a, b, kind});
+        if (t.spans.size() >= kMaxPendingSpans) { t.drain_locked(); }
     }
 };
 
 // ---------------------------------------------------------------- host bit I/O
-// bitstream.h:28-63 / :65-103, memory mode, used only for the stream headers.
+// bitstream.h:28-63 / :65-103, both modes, used only for the stream headers.
+bool writer_is_memory(const bitstream* bs) { return bs->data != NULL && bs->capacity > 0; }     // bitstream.h:34
+bool writer_is_callback(const bitstream* bs) { return bs->data == NULL && bs->capacity == 0 && bs->output != NULL; }
+bool reader_is_callback(const bitstream* bs) { return bs->data == NULL && bs->bytes == 0 && bs->input != NULL; }
+
 void host_put_bit(bitstream* bs, int bit) {
     if (bs->error != 0) { return; }
     bs->b64 = (bs->b64 << 1) | (uint64_t)(bit & 1);
     if (++bs->bits == 64) {
-        if (bs->data == NULL || bs->capacity == 0) { bs->error = EINVAL; return; }
-        for (int k = 0; k < 8 && bs->error == 0; k++) {
-            if (bs->bytes == bs->capacity) { bs->error = E2BIG; }
-            else { bs->data[bs->bytes++] = (uint8_t)(bs->b64 >> (56 - 8 * k)); }
+        if (writer_is_memory(bs)) {
+            for (int k = 0; k < 8 && bs->error == 0; k++) {
+                if (bs->bytes == bs->capacity) { bs->error = E2BIG; }
+                else { bs->data[bs->bytes++] = (uint8_t)(bs->b64 >> (56 - 8 * k)); }
+            }
+        } else if (writer_is_callback(bs)) {                    // bitstream.h:44-48
+            bs->error = bs->output(bs);
+            if (bs->error == 0) { bs->bytes += 8; }
+        } else {
+            bs->error = EINVAL;
         }
         bs->bits = 0;
         bs->b64 = 0;
@@ -135,12 +162,18 @@ uint64_t reader_limit(const bitstream* bs) { return bs->bytes != 0 ? bs->bytes :
 int host_get_bit(bitstream* bs) {
     if (bs->error != 0) { return 0; }
     if (bs->bits == 0) {
-        if (bs->data == NULL) { bs->error = EINVAL; return 0; }
-        const uint64_t limit = reader_limit(bs);
         bs->b64 = 0;
-        for (int k = 0; k < 8 && bs->error == 0; k++) {
-            if (bs->read == limit) { bs->error = E2BIG; }
-            else { bs->b64 |= (uint64_t)bs->data[bs->read++] << (56 - 8 * k); }
+        if (bs->data != NULL) {
+            const uint64_t limit = reader_limit(bs);
+            for (int k = 0; k < 8 && bs->error == 0; k++) {
+                if (bs->read == limit) { bs->error = E2BIG; }
+                else { bs->b64 |= (uint64_t)bs->data[bs->read++] << (56 - 8 * k); }
+            }
+        } else if (reader_is_callback(bs)) {                    // bitstream.h:81-85
+            bs->error = bs->input(bs);
+            if (bs->error == 0) { bs->read += 8; }
+        } else {
+            bs->error = EINVAL;
         }
         bs->bits = 64;
     }
@@ -154,6 +187,16 @@ uint64_t host_get_bits(bitstream* bs, int n) {
     uint64_t v = 0;
     for (int b = 0; b < n && bs->error == 0; b++) { v |= (uint64_t)host_get_bit(bs) << b; }
     return v;
+}
+
+uint64_t load_be64(const uint8_t* p) {
+    uint64_t w = 0;
+    for (int k = 0; k < 8; k++) { w = (w << 8) | p[k]; }
+    return w;
+}
+
+void store_be64(uint8_t* p, uint64_t w) {
+    for (int k = 0; k < 8; k++) { p[k] = (uint8_t)(w >> (56 - 8 * k)); }
 }
 
 bool window_ok(uint32_t w) { return w >= 2 && w <= 32768; }
@@ -181,13 +224,16 @@ uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 // match finder of encode stage 1: 1 = indexed (default), 0 = brute-force scan
 // (SQZ_FINDER=scan|index).  Both produce the reference's tokens.
-int g_finder = -1;      // -1 = not chosen yet
+std::atomic<int> g_finder{-1};      // -1 = not chosen yet
 int finder_default() {
-    if (g_finder < 0) {
+    int f = g_finder.load(std::memory_order_relaxed);
+    if (f < 0) {
         const char* e = getenv("SQZ_FINDER");
-        g_finder = (e != NULL && strcmp(e, "scan") == 0) ? 0 : 1;
+        const int chosen = (e != NULL && strcmp(e, "scan") == 0) ? 0 : 1;
+        // a concurrent sqz_hip_set_finder wins over the environment's default
+        f = g_finder.compare_exchange_strong(f, chosen) ? chosen : g_finder.load();
     }
-    return g_finder;
+    return f;
 }
 
 uint32_t match_groups_for(uint64_t avg_block_bytes) {
@@ -200,18 +246,19 @@ uint32_t match_groups_for(uint64_t avg_block_bytes) {
 // stage 1 on device buffers -> token words; work = 2 arrays of one uint32 slot per input byte
 void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint32_t n,
                 uint32_t window, uint32_t* tokens, uint32_t* counts,
-                uint32_t* work_a, uint32_t* work_m, uint64_t avg_block, hipStream_t st) {
+                uint32_t* work_a, uint32_t* work_m, uint64_t avg_block, uint64_t slots,
+                hipStream_t st) {
     if (finder == 0 || work_a == nullptr || work_m == nullptr) {
         SpanGuard g(st, SQZ_HIP_K_LZ77_SCAN);
-        sqzk::launch_lz77_scan(d_in, d_in_off, n, window, tokens, counts, scan_waves(), st);
+        sqzk::launch_lz77_scan(d_in, d_in_off, n, window, tokens, counts, scan_waves(), slots, st);
     } else {
         { SpanGuard g(st, SQZ_HIP_K_INDEX_SORT);
-          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, st); }
+          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, slots, st); }
         { SpanGuard g(st, SQZ_HIP_K_INDEX_MATCH);
           sqzk::launch_index_match(d_in, d_in_off, n, window, work_a, work_m,
-                                   match_groups_for(avg_block), st); }
+                                   match_groups_for(avg_block), slots, st); }
         { SpanGuard g(st, SQZ_HIP_K_INDEX_PARSE);
-          sqzk::launch_index_parse(d_in, d_in_off, n, work_m, tokens, counts, st); }
+          sqzk::launch_index_parse(d_in, d_in_off, n, work_m, tokens, counts, slots, st); }
     }
 }
 
@@ -220,8 +267,8 @@ void run_encode(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
                 uint32_t window, uint32_t* tokens, uint32_t* counts, uint32_t* work_a,
                 uint32_t* work_m, uint64_t avg_block, uint8_t* d_out, const uint64_t* d_out_off,
                 uint64_t* d_out_bytes, int32_t* d_err, uint64_t prefix_acc, int prefix_fill,
-                hipStream_t st) {
-    run_stage1(finder, d_in, d_in_off, n, window, tokens, counts, work_a, work_m, avg_block, st);
+                uint64_t slots, hipStream_t st) {
+    run_stage1(finder, d_in, d_in_off, n, window, tokens, counts, work_a, work_m, avg_block, slots, st);
     SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
     sqzk::launch_huffman_emit(tokens, d_in_off, counts, d_out, d_out_off, d_out_bytes, d_err, n,
                               prefix_acc, prefix_fill, st);
@@ -255,15 +302,34 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     run_encode(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
                (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
                (uint32_t*)c.work_m.p, widest, (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
-               (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, st);
+               (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, total_in + 64, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_bytes, c.out_bytes.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (uint32_t b = 0; b < n; b++) {
-        if (out_bytes[b] > 0) {
-            HIP_TRY(hipMemcpyAsync(out + out_off[b], (const uint8_t*)c.out.p + oo[b], out_bytes[b],
-                                   hipMemcpyDeviceToHost, st));
+    // the streams leave as ONE transfer: packed back to back on the device first (the slabs are
+    // sized for the worst case, 2.3 x what a Zipf block produces), then spread over the caller's
+    // slabs on the host.  Only out[out_off[b] .. + out_bytes[b]) is written.
+    std::vector<uint64_t> dense_off(n + 1);
+    dense_off[0] = 0;
+    for (uint32_t b = 0; b < n; b++) { dense_off[b + 1] = dense_off[b] + ((out_bytes[b] + 7) & ~7ull); }
+    const uint64_t dense_total = dense_off[n];
+    if (dense_total > 0) {
+        if (n == 1) {
+            HIP_TRY(hipMemcpyAsync(out + out_off[0], c.out.p, out_bytes[0], hipMemcpyDeviceToHost, st));
+        } else {
+            if ((e = c.dense.reserve(dense_total + 16)) || (e = c.dense_off.reserve((n + 1) * 8))) { return e; }
+            HIP_TRY(hipMemcpyAsync(c.dense_off.p, dense_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+            sqzk::launch_compact_blocks((const uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
+                                        (const uint64_t*)c.out_bytes.p, n, (uint8_t*)c.dense.p,
+                                        (const uint64_t*)c.dense_off.p, dense_total / n, st);
+            HIP_TRY(hipGetLastError());
+            if (c.host_dense.size() < dense_total) { c.host_dense.resize(dense_total); }
+            HIP_TRY(hipMemcpyAsync(c.host_dense.data(), c.dense.p, dense_total, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint32_t b = 0; b < n; b++) {
+                memcpy(out + out_off[b], c.host_dense.data() + dense_off[b], out_bytes[b]);
+            }
         }
     }
     if (tokens_total != nullptr) {
@@ -389,65 +455,155 @@ void sqz_read_header_h0(struct bitstream* bs, uint64_t* bytes, uint8_t* win_bits
 void sqz_compress(struct sqz* s, struct bitstream* bs,
                   const uint8_t* data, size_t bytes, uint32_t window) {
     if (s == NULL || bs == NULL) { return; }
+    s->bs = bs;                                          // squeeze.h:332
     if (s->error != 0) { return; }                       // sticky: squeeze.h:337
     if (bs->error != 0) { s->error = bs->error; return; } // squeeze.h:226-227
-    if (!window_ok(window) || bs->data == NULL || bs->capacity == 0 ||
-        (bytes > 0 && data == NULL) || bytes > kMaxStream || bs->bytes > bs->capacity) {
+    const bool by_callback = writer_is_callback(bs);
+    if (!window_ok(window) || (!by_callback && !writer_is_memory(bs)) ||
+        (bytes > 0 && data == NULL) || bytes > kMaxStream || (!by_callback && bs->bytes > bs->capacity) ||
+        bs->bits < 0 || bs->bits > 63) {
         s->error = EINVAL;
         return;
     }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int e = probe_locked(c);
-    if (e != 0) { s->error = e; return; }
+    // callback mode: the stream lands in a buffer of ours and is handed over word by word below
+    std::vector<uint8_t> own;
+    uint8_t* dst = by_callback ? nullptr : bs->data + bs->bytes;
+    uint64_t room = by_callback ? 0 : bs->capacity - bs->bytes;
+    if (by_callback) {
+        room = sqz_bound(bytes) + 16;
+        own.resize(room);
+        dst = own.data();
+    }
     const uint64_t in_off[2] = {0, (uint64_t)bytes};
-    const uint64_t room = bs->capacity - bs->bytes;
     const uint64_t out_off[2] = {0, room};
     uint64_t produced = 0;
     int32_t err = 0;
-    // the device writes into a staging slab; it lands behind the header bytes
-    e = encode_host_locked(c, data, in_off, 1, window, bs->data + bs->bytes, out_off,
-                           &produced, &err, bs->b64, bs->bits, &s->tokens);
-    if (e != 0) { s->error = e; return; }
-    bs->bytes += produced;
+    {
+        Ctx& c = ctx();
+        std::lock_guard<std::mutex> g(c.mu);
+        int e = probe_locked(c);
+        if (e != 0) { s->error = e; return; }
+        // the device writes into a staging slab; it lands behind the header bytes
+        e = encode_host_locked(c, data, in_off, 1, window, dst, out_off, &produced, &err,
+                               bs->b64, bs->bits, &s->tokens);
+        if (e != 0) { s->error = e; return; }
+    }
     bs->b64 = 0;
     bs->bits = 0;
-    if (err == E2BIG) { bs->error = E2BIG; }
+    if (by_callback) {                                   // bitstream.h:44-48, one call per word
+        for (uint64_t k = 0; k + 8 <= produced && bs->error == 0; k += 8) {
+            bs->b64 = load_be64(dst + k);
+            bs->error = bs->output(bs);
+            if (bs->error == 0) { bs->bytes += 8; }
+            bs->b64 = 0;
+        }
+        if (err == 0) { err = bs->error; }               // squeeze.h:226-236 mirrors the stream's error
+    } else {
+        bs->bytes += produced;
+        if (err == E2BIG) { bs->error = E2BIG; }
+    }
     s->error = err;
+}
+
+// leave the reader where the reference's would be after the symbol that ended at `end_bit`
+// of buf[0 .. limit): bitstream.h:65-93 (the last fetched word, shifted by what was consumed)
+static void park_reader(bitstream* bs, const uint8_t* buf, uint64_t limit, uint64_t end_bit,
+                        uint64_t* words_out) {
+    const uint64_t words = (end_bit + 63) / 64;
+    bs->bits = (int32_t)(words * 64 - end_bit);
+    bs->b64 = 0;
+    if (bs->bits > 0 && words * 8 <= limit) { bs->b64 = load_be64(buf + (words - 1) * 8) << (64 - bs->bits); }
+    *words_out = words;
+}
+
+static void decompress_by_callback(struct sqz* s, struct bitstream* bs, uint8_t* data, size_t bytes) {
+    // What the header reader left: `bits` unread bits at the top of b64.  They become word 0 of
+    // our buffer (the bits in front of them are gone; the decoder starts behind them).
+    std::vector<uint8_t> buf;
+    uint64_t start_bit = 0;
+    if (bs->bits > 0) {
+        buf.resize(8);
+        store_be64(buf.data(), bs->b64 >> (64 - bs->bits));
+        start_bit = 64 - (uint64_t)bs->bits;
+    }
+    const uint64_t head_words = buf.size() / 8;
+    const uint64_t most_words = head_words + (sqz_bound(bytes) + 16) / 8 + 2;   // no stream of `bytes` bytes is longer
+    uint64_t want_words = head_words + bytes / 32 + 4;   // first guess: a quarter of the size
+    int src_error = 0;
+    bool dry = false;
+    for (;;) {
+        if (want_words > most_words) { want_words = most_words; }
+        while (buf.size() / 8 < want_words && !dry) {        // bitstream.h:81-85
+            bs->b64 = 0;
+            const int e = bs->input(bs);
+            if (e != 0) { src_error = e; dry = true; break; }
+            const size_t at = buf.size();
+            buf.resize(at + 8);
+            store_be64(buf.data() + at, bs->b64);
+        }
+        const uint64_t limit = buf.size();
+        const uint64_t in_off[2] = {0, limit};
+        const uint64_t out_off[2] = {0, (uint64_t)bytes};
+        int32_t err = 0;
+        uint64_t end_bit = 0;
+        {
+            Ctx& c = ctx();
+            std::lock_guard<std::mutex> g(c.mu);
+            int e = probe_locked(c);
+            if (e == 0) { e = decode_host_locked(c, buf.data(), in_off, 1, data, out_off, &err, start_bit, &end_bit); }
+            if (e != 0) { s->error = e; return; }
+        }
+        if (err == E2BIG && !dry && limit / 8 < most_words) {   // ran out of words: pull more and decode again
+            want_words = 2 * (limit / 8) + 4;
+            continue;
+        }
+        uint64_t words = 0;
+        park_reader(bs, buf.data(), limit, end_bit, &words);
+        if (words > limit / 8) { words = limit / 8; }
+        bs->read += 8 * (words - head_words);                // what the reference's reader would have fetched
+        if (err == E2BIG) {                                  // the source ended before the stream did
+            bs->error = src_error != 0 ? src_error : E2BIG;
+            err = bs->error;
+        }
+        s->error = err;
+        return;
+    }
 }
 
 void sqz_decompress(struct sqz* s, struct bitstream* bs, uint8_t* data, size_t bytes) {
     if (s == NULL || bs == NULL) { return; }
+    s->bs = bs;                                          // squeeze.h:504
     if (s->error != 0) { return; }
     if (bs->error != 0) { s->error = bs->error; return; }
+    if ((bytes > 0 && data == NULL) || bytes > kMaxStream || bs->bits < 0 || bs->bits > 63) {
+        s->error = EINVAL;
+        return;
+    }
+    if (reader_is_callback(bs)) {
+        if (bytes != 0) { decompress_by_callback(s, bs, data, bytes); }
+        return;
+    }
     const uint64_t limit = reader_limit(bs);
-    if (bs->data == NULL || (bytes > 0 && data == NULL) || bytes > kMaxStream ||
-        bs->read > limit || (uint64_t)bs->bits > bs->read * 8) {
+    if (bs->data == NULL || bs->read > limit || (uint64_t)bs->bits > bs->read * 8) {
         s->error = EINVAL;
         return;
     }
     if (bytes == 0) { return; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int e = probe_locked(c);
-    if (e != 0) { s->error = e; return; }
     const uint64_t start_bit = bs->read * 8 - (uint64_t)bs->bits;
     const uint64_t in_off[2] = {0, limit};
     const uint64_t out_off[2] = {0, (uint64_t)bytes};
     int32_t err = 0;
     uint64_t end_bit = 0;
-    e = decode_host_locked(c, bs->data, in_off, 1, data, out_off, &err, start_bit, &end_bit);
-    if (e != 0) { s->error = e; return; }
-    // leave the reader where the reference's would be (bitstream.h:65-93)
-    const uint64_t words = (end_bit + 63) / 64;
-    bs->read = words * 8 <= limit ? words * 8 : limit;
-    bs->bits = (int32_t)(words * 64 - end_bit);
-    bs->b64 = 0;
-    if (bs->bits > 0 && words * 8 <= limit) {
-        uint64_t w = 0;
-        for (int k = 0; k < 8; k++) { w |= (uint64_t)bs->data[(words - 1) * 8 + k] << (56 - 8 * k); }
-        bs->b64 = w << (64 - bs->bits);
+    {
+        Ctx& c = ctx();
+        std::lock_guard<std::mutex> g(c.mu);
+        int e = probe_locked(c);
+        if (e == 0) { e = decode_host_locked(c, bs->data, in_off, 1, data, out_off, &err, start_bit, &end_bit); }
+        if (e != 0) { s->error = e; return; }
     }
+    uint64_t words = 0;
+    park_reader(bs, bs->data, limit, end_bit, &words);
+    bs->read = words * 8 <= limit ? words * 8 : limit;
     if (err == E2BIG) { bs->error = E2BIG; }
     s->error = err;
 }
@@ -524,7 +680,8 @@ int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, 
     const int e = device_ready();
     if (e != 0) { return e; }
     run_stage1(0, (const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
-               nullptr, nullptr, 0, (hipStream_t)stream);
+               nullptr, nullptr, 0, ~0ull /* d_tokens: one slot per input byte, by contract */,
+               (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
@@ -543,7 +700,7 @@ int sqz_hip_lz77_blocks_ex(const void* d_in, const uint64_t* d_in_off, uint32_t 
     uint32_t* wm = wa != nullptr ? wa + slots : nullptr;
     run_stage1(finder, (const uint8_t*)d_in, d_in_off, n, window, d_tokens, d_token_count,
                finder == 1 ? wa : nullptr, finder == 1 ? wm : nullptr,
-               slots / (n > 0 ? n : 1), (hipStream_t)stream);
+               slots / (n > 0 ? n : 1), finder == 1 ? slots : ~0ull, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
@@ -567,10 +724,15 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
                           int32_t* d_err, void* d_scratch, uint64_t scratch_bytes, void* stream) {
     if (n == 0) { return 0; }
     if (d_scratch == NULL || scratch_bytes < sqz_hip_encode_scratch_bytes(n, 0)) { return EINVAL; }
-    if (d_in == NULL || d_in_off == NULL || !window_ok(window)) { return EINVAL; }
+    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL ||
+        d_out_bytes == NULL || d_err == NULL || !window_ok(window)) { return EINVAL; }
     int e = device_ready();
     if (e != 0) { return e; }
     const uint64_t head = align_up((uint64_t)n * 4, 256);
+    // The offsets live on the device, so whether in_off[n] fits the scratch cannot be checked here
+    // without a round trip: the kernels get `slots` and refuse (EINVAL, that block only) any
+    // block whose in_off[b+1] lies beyond it.  Offsets are absolute slot indices: in_off[0]
+    // need not be 0, but the arrays are addressed by them.
     const uint64_t slots = (scratch_bytes - head) / 12;    // >= total_in_bytes + 64 by contract
     uint32_t* counts = (uint32_t*)d_scratch;
     uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + head);
@@ -578,7 +740,7 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     uint32_t* work_m = work_a + slots;
     run_encode(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
                work_a, work_m, slots / n, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, 0, 0,
-               (hipStream_t)stream);
+               slots, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
@@ -606,7 +768,20 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     return hip_errno(hipGetLastError());
 }
 
-void sqz_hip_set_finder(int finder) { g_finder = finder == 0 ? 0 : 1; }
+int sqz_hip_pack_blocks(const void* d_slabs, const uint64_t* d_slab_off, const uint64_t* d_bytes,
+                        uint32_t n, void* d_dense, const uint64_t* d_dense_off,
+                        uint64_t avg_bytes, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_slabs == NULL || d_slab_off == NULL || d_bytes == NULL || d_dense == NULL ||
+        d_dense_off == NULL) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    sqzk::launch_compact_blocks((const uint8_t*)d_slabs, d_slab_off, d_bytes, n, (uint8_t*)d_dense,
+                                d_dense_off, avg_bytes, (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+void sqz_hip_set_finder(int finder) { g_finder.store(finder == 0 ? 0 : 1); }
 int  sqz_hip_get_finder(void) { return finder_default(); }
 
 // ------------------------------------------------------------------ timing
@@ -619,15 +794,7 @@ void sqz_hip_set_timing(int enabled) {
 int sqz_hip_get_timing(sqz_hip_timing* out, int reset) {
     Timing& t = timing();
     std::lock_guard<std::mutex> g(t.mu);
-    for (TimedSpan& s : t.spans) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-            if (s.kind >= 0 && s.kind < SQZ_HIP_KERNELS) { t.acc.ms[s.kind] += ms; t.acc.launches[s.kind]++; }
-        }
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
-    }
-    t.spans.clear();
+    t.drain_locked();
     if (out != NULL) { *out = t.acc; }
     if (reset) { t.acc = sqz_hip_timing{}; }
     return 0;

@@ -169,7 +169,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 dist += (int)r.get_lsb(xb);
                 if (r.overrun()) { err = kE2BIG; return; }
             }
-            if ((uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; return; }
+            // squeeze.h:534-541: 0 < pos <= 0x7FFF (code 29 with all 13 extra bits set is 32768)
+            if (dist > 0x7FFF || (uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; return; }
             word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
             i += (uint64_t)len;
         }
@@ -285,7 +286,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             more_bits += (uint32_t)xb;
             uint32_t word = node;
             if (is_len) {
-                bad = pos_bad | (len > (uint32_t)kLenMax);
+                bad = pos_bad | (len > (uint32_t)kLenMax) | (dist > 0x7FFFu);    // squeeze.h:534: pos <= 0x7FFF
                 esc = pos_esc;
                 used += more_bits;
                 word = kTokMatch | (len << 16) | dist;

@@ -88,10 +88,11 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
                        uint32_t n_blocks,
                        uint32_t* __restrict__ buf_a,      // result lands here
                        uint32_t* __restrict__ buf_b,
-                       uint32_t* __restrict__ tmp) {      // 4 bytes per position of scratch
+                       uint32_t* __restrict__ tmp,        // 4 bytes per position of scratch
+                       uint64_t slots) {
     __shared__ SortLds lds;
     const uint32_t b = blockIdx.x;
-    if (b >= n_blocks) { return; }
+    if (b >= n_blocks || in_off[b + 1] > slots) { return; }   // beyond the caller's arrays: index_parse refuses the block
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,7 +234,7 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                         const uint64_t* __restrict__ in_off,
                         uint32_t n_blocks, uint32_t window,
                         const uint32_t* __restrict__ sorted,
-                        uint32_t* __restrict__ match, uint32_t groups) {
+                        uint32_t* __restrict__ match, uint32_t groups, uint64_t slots) {
     // A stream's workgroups all run on ONE XCD, one stream after the other: workgroup k is
     // dispatched to XCD k % 8, so stream b = 8 * (k / 8 / groups) + k % 8.  Its bytes and
     // sorted positions (~1.3 MB for 256 KB) then stay in that XCD's 4 MB L2 while they are
@@ -246,7 +247,7 @@ void index_match_kernel(const uint8_t* __restrict__ in,
     const uint32_t local = blockIdx.x / (uint32_t)kXcds;
     const uint32_t b = (local / groups) * (uint32_t)kXcds + xcd;
     const uint32_t group = local % groups;
-    if (b >= n_blocks) { return; }
+    if (b >= n_blocks || in_off[b + 1] > slots) { return; }
     const uint8_t* src = in + in_off[b];
     const uint64_t bytes = in_off[b + 1] - in_off[b];
     if (bytes < 3) { return; }
@@ -392,11 +393,15 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
                         uint32_t n_blocks,
                         const uint32_t* __restrict__ match,
                         uint32_t* __restrict__ tokens,
-                        uint32_t* __restrict__ tok_count) {
+                        uint32_t* __restrict__ tok_count, uint64_t slots) {
     __shared__ ParseLds lds;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
     const int lane = threadIdx.x;
+    if (in_off[b + 1] > slots) {                  // the caller's arrays do not reach this far: refuse the block
+        if (lane == 0) { tok_count[b] = kRefused; }
+        return;
+    }
     const uint8_t* src = in + in_off[b];
     const uint64_t bytes = in_off[b + 1] - in_off[b];
     const uint32_t* M = match + in_off[b];
@@ -482,29 +487,30 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
 }
 
 void launch_index_sort(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
-                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, hipStream_t stream) {
+                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, uint64_t slots,
+                       hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(index_sort_kernel, dim3(n_blocks), dim3(kSortThreads), 0, stream,
-                       in, in_off, n_blocks, buf_a, buf_b, tmp);
+                       in, in_off, n_blocks, buf_a, buf_b, tmp, slots);
 }
 
 void launch_index_match(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                         uint32_t window, const uint32_t* sorted, uint32_t* match,
-                        uint32_t match_groups, hipStream_t stream) {
+                        uint32_t match_groups, uint64_t slots, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     if (match_groups < 1) { match_groups = 1; }
     const uint32_t rounded = (n_blocks + (uint32_t)kXcds - 1) / (uint32_t)kXcds * (uint32_t)kXcds;
     while ((uint64_t)match_groups * rounded > 0x7FFFFFFFull) { match_groups = (match_groups + 1) / 2; }
     hipLaunchKernelGGL(index_match_kernel, dim3(rounded * match_groups), dim3(256), 0, stream,
-                       in, in_off, n_blocks, window, sorted, match, match_groups);
+                       in, in_off, n_blocks, window, sorted, match, match_groups, slots);
 }
 
 void launch_index_parse(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                         const uint32_t* match, uint32_t* tokens, uint32_t* tok_count,
-                        hipStream_t stream) {
+                        uint64_t slots, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(index_parse_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       in, in_off, n_blocks, match, tokens, tok_count);
+                       in, in_off, n_blocks, match, tokens, tok_count, slots);
 }
 
 } // namespace sqzk

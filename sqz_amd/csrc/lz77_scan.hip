@@ -71,7 +71,7 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
                       const uint64_t* __restrict__ in_off,
                       uint32_t n_blocks, uint32_t window,
                       uint32_t* __restrict__ tokens,
-                      uint32_t* __restrict__ tok_count) {
+                      uint32_t* __restrict__ tok_count, uint64_t slots) {
     __shared__ ScanLds lds;
     uint8_t* const buf = lds.buf;
     const int tid = threadIdx.x;
@@ -79,6 +79,10 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
+    if (in_off[b + 1] > slots) {                  // the caller's arrays do not reach this far: refuse the block
+        if (tid == 0) { tok_count[b] = kRefused; }
+        return;
+    }
 
     const uint8_t* src = in + in_off[b];
     const uint64_t bytes = in_off[b + 1] - in_off[b];
@@ -302,24 +306,24 @@ void lz77_scan_kernel(const uint8_t* __restrict__ in,
 
 void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                       uint32_t window, uint32_t* tokens, uint32_t* tok_count,
-                      int waves_per_stream, hipStream_t stream) {
+                      int waves_per_stream, uint64_t slots, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     switch (waves_per_stream) {
     case 1:
         hipLaunchKernelGGL(lz77_scan_kernel<1>, dim3(n_blocks), dim3(kWave), 0, stream,
-                           in, in_off, n_blocks, window, tokens, tok_count);
+                           in, in_off, n_blocks, window, tokens, tok_count, slots);
         break;
     case 2:
         hipLaunchKernelGGL(lz77_scan_kernel<2>, dim3(n_blocks), dim3(2 * kWave), 0, stream,
-                           in, in_off, n_blocks, window, tokens, tok_count);
+                           in, in_off, n_blocks, window, tokens, tok_count, slots);
         break;
     case 8:
         hipLaunchKernelGGL(lz77_scan_kernel<8>, dim3(n_blocks), dim3(8 * kWave), 0, stream,
-                           in, in_off, n_blocks, window, tokens, tok_count);
+                           in, in_off, n_blocks, window, tokens, tok_count, slots);
         break;
     default:
         hipLaunchKernelGGL(lz77_scan_kernel<4>, dim3(n_blocks), dim3(4 * kWave), 0, stream,
-                           in, in_off, n_blocks, window, tokens, tok_count);
+                           in, in_off, n_blocks, window, tokens, tok_count, slots);
         break;
     }
 }

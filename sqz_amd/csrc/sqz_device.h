@@ -47,6 +47,7 @@ constexpr int kEINVAL = 22;
 constexpr int kE2BIG  = 7;
 
 constexpr uint32_t kTokMatch = 0x80000000u;
+constexpr uint32_t kRefused = 0xFFFFFFFFu;    // tok_count of a block stage 1 would not touch (offsets beyond the scratch)
 
 // ---------------------------------------------------------------------------
 // DEFLATE length / distance codes by arithmetic (squeeze.h:29-79 tables and

@@ -11,21 +11,25 @@ namespace sqzk {
 // in[in_off[b] .. in_off[b+1]) and writes its token words at
 // tokens + in_off[b]; the count goes to tok_count[b].
 // waves_per_stream: 1, 2, 4 (default) or 8 wavefronts share one stream's window.
+// slots: how many uint32 slots the per-byte arrays (tokens, buf_a, buf_b, match) hold; a block
+// whose in_off[b+1] lies beyond them is refused (tok_count[b] = kRefused -> EINVAL in stage 2)
+// instead of being written out of bounds.
 void launch_lz77_scan(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                       uint32_t window, uint32_t* tokens, uint32_t* tok_count,
-                      int waves_per_stream, hipStream_t stream);
+                      int waves_per_stream, uint64_t slots, hipStream_t stream);
 
 // stage 1, indexed form: same tokens as launch_lz77_scan without visiting every
 // distance (lz77_index.hip): sort -> match -> parse.  buf_a / buf_b / match: one
 // uint32 slot per input byte each, addressed like `tokens`.
 void launch_index_sort(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
-                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, hipStream_t stream);
+                       uint32_t* buf_a, uint32_t* buf_b, uint32_t* tmp, uint64_t slots,
+                       hipStream_t stream);
 void launch_index_match(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                         uint32_t window, const uint32_t* sorted, uint32_t* match,
-                        uint32_t match_groups, hipStream_t stream);
+                        uint32_t match_groups, uint64_t slots, hipStream_t stream);
 void launch_index_parse(const uint8_t* in, const uint64_t* in_off, uint32_t n_blocks,
                         const uint32_t* match, uint32_t* tokens, uint32_t* tok_count,
-                        hipStream_t stream);
+                        uint64_t slots, hipStream_t stream);
 
 // stage 2: adaptive-Huffman emit (squeeze.h:278-315, huffman.h, bitstream.h)
 void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
@@ -41,5 +45,11 @@ void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint
                            uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
 void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,
                       const uint64_t* out_off, uint32_t n_blocks, hipStream_t stream);
+
+// slabs -> dense image of a batch's streams (blocks.hip): block b moves from src + src_off[b]
+// to dst + dst_off[b].  bytes[b] and all offsets are multiples of 8.
+void launch_compact_blocks(const uint8_t* src, const uint64_t* src_off, const uint64_t* bytes,
+                           uint32_t n_blocks, uint8_t* dst, const uint64_t* dst_off,
+                           uint64_t avg_bytes, hipStream_t stream);
 
 } // namespace sqzk

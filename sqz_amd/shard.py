@@ -30,6 +30,9 @@ def scatter_blocks(root_blocks, n_blocks: int, block_bytes: int, device, group=N
         chunks = []
         for r in range(world):
             lo, hi = block_range(n_blocks, r, world)
+            if hi - lo == widest:                    # the usual case (4096 / 1,2,4,8): no copy
+                chunks.append(root_blocks[lo * block_bytes:hi * block_bytes])
+                continue
             c = torch.zeros(widest * block_bytes, dtype=torch.uint8, device=device)
             c[:(hi - lo) * block_bytes] = root_blocks[lo * block_bytes:hi * block_bytes]
             chunks.append(c)
@@ -64,6 +67,56 @@ def gather_slabs(local_slabs, local_sizes, n_blocks: int, slab_bytes: int, devic
         slabs.append(slabs_list[r][:(hi - lo) * slab_bytes])
         sizes.append(sizes_list[r][:hi - lo])
     return torch.cat(slabs), torch.cat(sizes)
+
+
+def dense_offsets(sizes):
+    """int64[n] stream sizes -> int64[n+1] offsets of the dense image (every stream starts on an
+    8-byte boundary: sizes are multiples of 8 unless a stream was cut short by E2BIG)."""
+    aligned = (sizes + 7) // 8 * 8
+    off = torch.zeros(sizes.numel() + 1, dtype=torch.int64, device=sizes.device)
+    torch.cumsum(aligned, 0, out=off[1:])
+    return off
+
+
+def gather_dense(local_dense, local_sizes, n_blocks: int, device, group=None, dst=0):
+    """Variable-sized compressed streams back to `dst` in block order, without shipping the
+    worst-case slabs: every rank has packed its streams back to back (sqz_hip_pack_blocks),
+    `dst` first gathers the sizes (ncclGather shape, rccl.h:745), then receives every rank's
+    dense bytes with one point-to-point transfer per peer straight into its place in the
+    root image (grouped ncclSend / ncclRecv, rccl.h:700,722: one stream per xGMI link, no
+    ring).  local_dense: uint8[>= dense_offsets(local_sizes)[-1]].
+
+    Returns (dense uint8[total], sizes int64[n_blocks], offsets int64[n_blocks+1]) on dst and
+    (None, None, None) elsewhere; the triple is what sqz_hip_decode_blocks takes."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    widest = max(block_range(n_blocks, r, world)[1] - block_range(n_blocks, r, world)[0]
+                 for r in range(world))
+    pad_sizes = torch.zeros(widest, dtype=torch.int64, device=device)
+    pad_sizes[:local_sizes.numel()] = local_sizes.to(device)
+    sizes_list = [torch.empty_like(pad_sizes) for _ in range(world)] if rank == dst else None
+    dist.gather(pad_sizes, sizes_list, dst=dst, group=group)
+    if rank != dst:
+        total = int(dense_offsets(local_sizes)[-1])
+        if total > 0:
+            dist.send(local_dense[:total].to(device), dst=dst, group=group)
+        return None, None, None
+    sizes = torch.cat([sizes_list[r][:block_range(n_blocks, r, world)[1] - block_range(n_blocks, r, world)[0]]
+                       for r in range(world)])
+    off = dense_offsets(sizes)
+    host_off = off.cpu()
+    dense = torch.empty(int(host_off[-1]), dtype=torch.uint8, device=device)
+    ops = []
+    for r in range(world):
+        lo, hi = block_range(n_blocks, r, world)
+        a, b = int(host_off[lo]), int(host_off[hi])
+        if r == dst:
+            dense[a:b] = local_dense[:b - a].to(device)
+        elif b > a:
+            ops.append(dist.P2POp(dist.irecv, dense[a:b], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return dense, sizes, off
 
 
 def max_over_ranks(value: float, device, group=None) -> float:

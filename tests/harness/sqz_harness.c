@@ -9,12 +9,13 @@
  * skipped like file_exist() does, test.c:231).  The reference harness itself needs the
  * MSVC CRT (fopen_s, errno_t) and does not build on Linux.
  *
- * File mode: like the reference, every case is compressed INTO A FILE ("~compressed~.bin",
- * test.c:163) and verified FROM that file, and the file holds what the reference's harness
- * writes: the 64-bit words of the stream in host byte order (fwrite(&b64, 8, 1), test.c:39-42,
- * read back with fread, test.c:98-101).  The device cannot call back per word, so the stream
- * is produced in a host buffer (memory mode, bitstream.h:34-43) and sqz_file_words() turns it
- * into the file image (the .file images under tests/golden are the reference's own files).
+ * File mode, exactly as the reference does it: every case is compressed INTO A FILE
+ * ("~compressed~.bin", test.c:163) through a callback-mode bit stream
+ * `{ .stream = FILE*, .output = write_file }` whose callback fwrite()s `b64` in host byte
+ * order (test.c:39-42,53), and verified FROM that file through `{ .stream, .input = read_file }`
+ * (test.c:98-101,110).  The shim replays the device-produced stream through `.output` word by
+ * word and pulls words through `.input` (include/sqz/sqz.h); the .file images under
+ * tests/golden are the files the compiled reference wrote through the same callbacks.
  * locate_test_folder() (test.c:183-193) walks up until the corpus is found.
  * SQZ_HARNESS_KEEP=<dir> additionally keeps each named case as <dir>/<name>.w<bits>.file.
  *
@@ -49,98 +50,118 @@ static int read_fully(const char* fn, uint8_t** data, size_t* bytes) {
 
 static const char* compressed = "~compressed~.bin";                    /* test.c:163 */
 
-static int write_image(const char* to, const uint8_t* image, uint64_t bytes) {
-    FILE* out = fopen(to, "wb");                                       /* test.c:47 */
-    if (out == NULL) { printf("Failed to create \"%s\": %s\n", to, strerror(errno)); return errno; }
-    int r = fwrite(image, 1, (size_t)bytes, out) == (size_t)bytes ? 0 : (errno != 0 ? errno : EIO);
-    if (fclose(out) != 0 && r == 0) {                                  /* test.c:72-76 */
-        r = errno;
-        printf("Failed to flush on file close: %s\n", strerror(r));
+static int write_file(bitstream* bs) {                                 /* test.c:39-42 */
+    return fwrite(&bs->b64, 8, 1, (FILE*)bs->stream) == 1 ? 0 : (errno != 0 ? errno : EIO);
+}
+
+static int read_file(bitstream* bs) {                                  /* test.c:98-101 */
+    return fread(&bs->b64, 8, 1, (FILE*)bs->stream) == 1 ? 0 : (errno != 0 ? errno : EIO);
+}
+
+static int copy_file(const char* from, const char* to) {
+    uint8_t* image = NULL; size_t n = 0;
+    int r = read_fully(from, &image, &n);
+    if (r != 0) { return r; }
+    FILE* out = fopen(to, "wb");
+    if (out == NULL) { r = errno; }
+    else {
+        if (fwrite(image, 1, n, out) != n) { r = errno != 0 ? errno : EIO; }
+        if (fclose(out) != 0 && r == 0) { r = errno; }
     }
+    free(image);
     return r;
 }
 
-/* test.c:44-96: header + payload through the vtable, then the file the reference writes */
+/* test.c:44-96: header + payload through the vtable into the file, word by word */
 static int compress(const char* from, const char* to, const uint8_t* data, size_t bytes) {
-    const uint64_t capacity = sqz_bound(bytes) + 16;
-    uint8_t* comp = (uint8_t*)malloc(capacity);
-    if (comp == NULL) { return ENOMEM; }
+    FILE* out = fopen(to, "wb");                                       /* test.c:46-51 */
+    if (out == NULL) {
+        const int e = errno;
+        printf("Failed to create \"%s\": %s\n", to, strerror(e));
+        return e;
+    }
     int r = 0;
-    bitstream bs = { .data = comp, .capacity = capacity };
-    squeeze.write_header(&bs, bytes, (uint8_t)bits_win);               /* test.c:54 */
-    if (bs.error != 0) { r = bs.error; }
     squeeze_type* s = NULL;
-    if (r == 0) {
-        s = squeeze.alloc(0);                                          /* test.c:59 */
-        if (s == NULL) { r = ENOMEM; printf("squeeze_new() failed.\n"); }
-    }
-    if (r == 0) {
-        squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << bits_win));   /* test.c:61 */
-        r = s->error;
-    }
-    if (s != NULL) { squeeze.free(s); s = NULL; }
-    if (r != 0) {
-        printf("Failed to compress: %s\n", strerror(r));
+    bitstream bs = { .stream = out, .output = write_file };            /* test.c:53 */
+    squeeze.write_header(&bs, bytes, (uint8_t)bits_win);               /* test.c:54 */
+    if (bs.error != 0) {
+        r = bs.error;
+        printf("Failed to create \"%s\": %s\n", to, strerror(r));
     } else {
-        r = sqz_file_words(comp, bs.bytes, comp);                      /* words in host order, in place */
-        if (r == 0) { r = write_image(to, comp, bs.bytes); }
-        const char* keep = getenv("SQZ_HARNESS_KEEP");
-        if (r == 0 && keep != NULL && from != NULL) {
-            const char* fn = strrchr(from, '/');                       /* basename, test.c:81-83 */
-            fn = fn != NULL ? fn + 1 : from;
-            char path[1024];
-            snprintf(path, sizeof(path), "%s/%s.w%d.file", keep, fn, bits_win);
-            r = write_image(path, comp, bs.bytes);
+        s = squeeze.alloc(0);                                          /* test.c:59 */
+        if (s != NULL) {
+            squeeze.compress(s, &bs, data, bytes, (uint16_t)(1u << bits_win));   /* test.c:61 */
+        } else {
+            r = ENOMEM;
+            printf("squeeze_new() failed.\n");
         }
+    }
+    const int rc = fclose(out) == 0 ? 0 : errno;                       /* test.c:70-76 */
+    if (rc != 0) {
+        printf("Failed to flush on file close: %s\n", strerror(rc));
+        if (r == 0) { r = rc; }
     }
     if (r == 0) {
-        const char* fn = from == NULL ? NULL : strrchr(from, '/');
-        fn = fn != NULL ? fn + 1 : from;
-        const double percent = bytes > 0 ? bs.bytes * 100.0 / (double)bytes : 0.0;
-        if (from != NULL) {                                            /* test.c:85-88 */
-            printf("%7lld -> %7lld %5.1f%% of \"%s\"\n", (long long)bytes, (long long)bs.bytes, percent, fn);
+        r = s->error;                                                  /* test.c:77-78 */
+        if (r != 0) {
+            printf("Failed to compress: %s\n", strerror(r));
         } else {
-            printf("%7lld -> %7lld %5.1f%%\n", (long long)bytes, (long long)bs.bytes, percent);
+            const char* fn = from == NULL ? NULL : strrchr(from, '/'); /* basename, test.c:81-83 */
+            fn = fn != NULL ? fn + 1 : from;
+            const uint64_t written = s->bs->bytes;                     /* test.c:84 */
+            const double percent = bytes > 0 ? written * 100.0 / (double)bytes : 0.0;
+            if (from != NULL) {                                        /* test.c:85-88 */
+                printf("%7lld -> %7lld %5.1f%% of \"%s\"\n", (long long)bytes, (long long)written, percent, fn);
+            } else {
+                printf("%7lld -> %7lld %5.1f%%\n", (long long)bytes, (long long)written, percent);
+            }
+            const char* keep = getenv("SQZ_HARNESS_KEEP");
+            if (keep != NULL && from != NULL) {
+                char path[1024];
+                snprintf(path, sizeof(path), "%s/%s.w%d.file", keep, fn, bits_win);
+                r = copy_file(to, path);
+            }
         }
     }
-    free(comp);
+    if (s != NULL) { squeeze.free(s); s = NULL; }                      /* test.c:92-94 */
     return r;
 }
 
-/* test.c:103-162: read the file back, decompress, compare */
+/* test.c:103-162: read the file back through the .input callback, decompress, compare */
 static int verify(const char* fn, const uint8_t* input, size_t size) {
-    uint8_t* image = NULL; size_t n_image = 0;
-    int r = read_fully(fn, &image, &n_image);
-    if (r != 0) { printf("Failed to open \"%s\"\n", fn); return r; }
-    uint8_t* back = (uint8_t*)malloc(size + 1);
-    if (back == NULL) { free(image); return ENOMEM; }
-    r = sqz_file_words(image, n_image, image);                         /* file words -> stream */
-    bitstream rd = { .data = image, .bytes = n_image };                /* test.c:110 */
-    uint64_t n = 0; uint8_t win_bits = 0;
+    FILE* in = fopen(fn, "rb");                                        /* test.c:105-109 */
+    if (in == NULL) { printf("Failed to open \"%s\"\n", fn); return errno; }
+    int r = 0;
+    bitstream bs = { .stream = in, .input = read_file };               /* test.c:110 */
+    uint64_t bytes = 0; uint8_t win_bits = 0;
+    squeeze.read_header(&bs, &bytes, &win_bits);                       /* test.c:114 */
+    if (bs.error != 0 || bytes != size || win_bits != bits_win) {
+        printf("Failed to read header from \"%s\"\n", fn);
+        r = bs.error != 0 ? bs.error : EINVAL;
+    }
+    uint8_t* back = NULL;
     if (r == 0) {
-        squeeze.read_header(&rd, &n, &win_bits);                       /* test.c:114 */
-        if (rd.error != 0 || n != size || win_bits != bits_win) {
-            printf("Failed to read header\n");
-            r = rd.error != 0 ? rd.error : EINVAL;
-        }
+        back = (uint8_t*)calloc(1, size + 1);                          /* test.c:127 */
+        if (back == NULL) { r = ENOMEM; }
     }
     if (r == 0) {
         squeeze_type* s = squeeze.alloc(0);                            /* test.c:121 */
-        if (s == NULL) { r = ENOMEM; }
+        if (s == NULL) { r = ENOMEM; printf("squeeze_new() failed.\n"); }
         else {
-            squeeze.decompress(s, &rd, back, (size_t)n);               /* test.c:134 */
+            squeeze.decompress(s, &bs, back, (size_t)bytes);           /* test.c:134 */
             r = s->error;
             squeeze.free(s);
         }
         if (r == 0 && memcmp(input, back, size) != 0) {                /* test.c:138-144 */
             size_t k = 0;
             while (k < size && input[k] == back[k]) { k++; }
-            printf("Decompressed data does not match input at offset %lld\n", (long long)k);
-            r = EINVAL;
+            printf("compress() and decompress() are not the same @%lld\n", (long long)k);
+            r = ENODATA;
         }
+        if (r != 0) { printf("Failed to decompress\n"); }
     }
+    fclose(in);
     free(back);
-    free(image);
     return r;
 }
 

@@ -146,6 +146,41 @@ def ref_compress(data: bytes, win_bits: int, header: bool) -> bytes:
     return out.raw[:n]
 
 
+class Stats(C.Structure):
+    """sqzo_stats of oracle/sqz_oracle.h"""
+    _fields_ = [(n, C.c_uint64) for n in ("lit_updates lit_swaps lit_moves pos_updates pos_swaps "
+                                          "pos_moves literal_bytes backref_bytes").split()] + \
+               [("lit_entropy", C.c_double), ("pos_entropy", C.c_double),
+                ("lit_depth", C.c_int32), ("pos_depth", C.c_int32)]
+
+
+def encode_tokens(tokens):
+    """stage 2 of the restatement alone on caller-made token words -> (errno, bytes, Stats)"""
+    toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+    cap = 8 * len(toks) + 64
+    out = C.create_string_buffer(cap)
+    n, st = C.c_uint64(0), Stats()
+    e = ORACLE.sqzo_encode_tokens(toks.ctypes.data_as(C.c_void_p), C.c_uint64(len(toks)), out,
+                                  C.c_uint64(cap), C.byref(n), C.byref(st))
+    return e, out.raw[:n.value], st
+
+
+def encode_stats(data: bytes, win_bits: int):
+    """payload-only encode + the counters of SURVEY.md section 8f-4 -> (bytes, Stats)"""
+    out = C.create_string_buffer(2 * len(data) + 1088)
+    n, st = C.c_uint64(0), Stats()
+    e = ORACLE.sqzo_encode_stats(data, C.c_uint64(len(data)), C.c_uint32(1 << win_bits), 0, out,
+                                 C.c_uint64(len(out)), C.byref(n), C.byref(st))
+    if e != 0:
+        raise OracleError(e, "oracle encode")
+    return out.raw[:n.value], st
+
+
+def golden_r2():
+    with open(os.path.join(GOLD, "golden_r2.json")) as fh:
+        return json.load(fh)
+
+
 def golden():
     with open(os.path.join(GOLD, "golden.json")) as fh:
         return json.load(fh)

@@ -93,3 +93,93 @@ def test_device_writes_and_reads_reference_files(v, tmp_path):
     assert sqz_amd.decompress(sqz_amd.file_words(path.read_bytes()), header=True) == data
     # a file written by the reference itself decodes on the device
     assert sqz_amd.decompress(sqz_amd.file_words(_read(v["image"])), header=True) == data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", FILE_MODE, ids=lambda v: f"w{v['win_bits']}")
+def test_callback_mode_streams(v):
+    """`.output` / `.input` bit streams (bitstream.h:16-17,44-48,81-85) through the shim: the
+    words handed to .output are the reference file's words, one call per word with the
+    reference's bookkeeping; a reader fed through .input decodes them, consumes what the
+    reference's reader would and never more than twice that from the source"""
+    import struct
+    from sqz_amd import _native as N
+    L = N.lib()
+    data = _read(v["file"], CORPUS)
+    image = _read(v["image"])                             # host-order words, as fwrite(&b64) left them
+    want = list(struct.unpack(f"={len(image) // 8}Q", image))
+    got, seen_bytes = [], []
+
+    @N.WORD_CALLBACK
+    def out_cb(bs):
+        got.append(bs.contents.b64)
+        seen_bytes.append(bs.contents.bytes)
+        return 0
+
+    w = N.Bitstream(output=out_cb)
+    L.sqz_write_header_h0(C.byref(w), len(data), v["win_bits"])
+    s = N.Sqz()
+    L.sqz_init(C.byref(s))
+    L.sqz_compress(C.byref(s), C.byref(w), data, len(data), 1 << v["win_bits"])
+    assert s.error == 0 and w.error == 0
+    assert got == want
+    assert seen_bytes == [8 * k for k in range(len(want))]        # bytes grows after each call
+    assert w.bytes == len(image) and s.bs.contents.bytes == len(image)   # attic test.c:84
+    assert (w.bits, w.b64) == (0, 0)
+
+    feed = list(want) + [0xDEADBEEFDEADBEEF] * (2 * len(want))   # junk behind the stream
+    pulled = []
+
+    @N.WORD_CALLBACK
+    def in_cb(bs):
+        bs.contents.b64 = feed[len(pulled)]
+        pulled.append(1)
+        return 0
+
+    r = N.Bitstream(input=in_cb)
+    n, wb = C.c_uint64(0), C.c_uint8(0)
+    L.sqz_read_header_h0(C.byref(r), C.byref(n), C.byref(wb))
+    assert (r.error, n.value, wb.value) == (0, len(data), v["win_bits"])
+    back = C.create_string_buffer(len(data))
+    d = N.Sqz()
+    L.sqz_init(C.byref(d))
+    L.sqz_decompress(C.byref(d), C.byref(r), back, len(data))
+    assert d.error == 0 and back.raw == data
+    assert r.read == len(image)                           # what the reference's reader fetches
+    assert len(want) <= len(pulled) <= 2 * len(want) + 8
+
+    # a source that ends too early: the callback's error is the stream's error (bitstream.h:83)
+    short = want[:len(want) // 2]
+    count = [0]
+
+    @N.WORD_CALLBACK
+    def dry_cb(bs):
+        if count[0] >= len(short):
+            return 5                                      # EIO
+        bs.contents.b64 = short[count[0]]
+        count[0] += 1
+        return 0
+
+    r2 = N.Bitstream(input=dry_cb)
+    L.sqz_read_header_h0(C.byref(r2), C.byref(n), C.byref(wb))
+    d2 = N.Sqz()
+    L.sqz_init(C.byref(d2))
+    L.sqz_decompress(C.byref(d2), C.byref(r2), back, len(data))
+    assert d2.error == 5 and r2.error == 5
+
+    # a sink that fails at the third word: two words accepted, the error sticks (bitstream.h:46-47)
+    acc = []
+
+    @N.WORD_CALLBACK
+    def full_cb(bs):
+        if len(acc) == 2:
+            return 28                                     # ENOSPC
+        acc.append(bs.contents.b64)
+        return 0
+
+    w3 = N.Bitstream(output=full_cb)
+    L.sqz_write_header_h0(C.byref(w3), len(data), v["win_bits"])
+    s3 = N.Sqz()
+    L.sqz_init(C.byref(s3))
+    L.sqz_compress(C.byref(s3), C.byref(w3), data, len(data), 1 << v["win_bits"])
+    assert (s3.error, w3.error, w3.bytes) == (28, 28, 16) and acc == want[:2]

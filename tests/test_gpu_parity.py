@@ -16,6 +16,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 G = O.golden()
+G2 = O.golden_r2()
 
 
 @pytest.fixture(scope="module")
@@ -211,9 +212,25 @@ def test_full_size_roundtrip_properties(sq, batch):
     sizes = out_bytes.cpu().numpy()
     assert (sizes % 8 == 0).all() and sizes.min() > 200000 and sizes.max() < 240000
     z = {x["block"]: x for x in G["zipf"] if x["in_bytes"] == bb}
-    for b in (0, 1):
+    # 42 blocks spread over 0..4095 against what the compiled reference produced for them
+    # (oracle/gen_golden_r2.py): encoder and decoder share the batched tree update, so the
+    # round trip below would not see a symmetric error in it -- these would
+    for x in G2["zipf_fullsize"]:
+        z[x["block"]] = x
+    assert len(z) >= 40
+    for b in sorted(z):
         got = out[int(out_off[b]):int(out_off[b]) + int(sizes[b])].cpu().numpy().tobytes()
-        assert len(got) == z[b]["out_bytes"] and O.fnv(got) == z[b]["out_fnv"]
+        assert O.fnv(d_in[b * bb:(b + 1) * bb].cpu().numpy().tobytes()) == z[b]["in_fnv"], b
+        assert len(got) == z[b]["out_bytes"] and O.fnv(got) == z[b]["out_fnv"], b
+    # the dense image (sqz_hip_pack_blocks) holds the same streams back to back and decodes too
+    dense, d_off = batch.pack_blocks(out, out_off, out_bytes)
+    assert int(d_off[-1]) == int(sizes.sum()) == dense.numel()
+    for b in (0, 1, 2047, 4095):
+        assert torch.equal(dense[int(d_off[b]):int(d_off[b + 1])], out[int(out_off[b]):int(out_off[b]) + int(sizes[b])])
+    d_back = torch.zeros_like(d_in)
+    derr = batch.decode_blocks(dense, d_off, n, d_back, off)
+    torch.cuda.synchronize()
+    assert int(derr.abs().sum()) == 0 and torch.equal(d_back, d_in)
     # decode straight from the slabs: block b's stream is [out_off[b], out_off[b] + size)
     # -> use slab offsets; the decoder needs only the start (size bounds the reads)
     d_back = torch.zeros_like(d_in)
@@ -415,3 +432,64 @@ def test_caller_tokens_are_validated(sq, batch):
             assert got == want, name
         else:
             assert err[b] == errno.EINVAL, (name, err[b])
+
+
+def test_distance_32768_is_refused(sq, batch):
+    """squeeze.h:534-541: 0 < pos <= 0x7FFF.  Distance code 29 with all 13 extra bits set is
+    32768 -- encodable by the tables, refused by the reference's decoder (EINVAL).  A stream
+    with >= 32768 literals in front of such a back reference, from the oracle's stage 2."""
+    rng = random.Random(5)
+    lits = [rng.randrange(256) for _ in range(33000)]
+    toks = np.array(lits + [0x80000000 | (3 << 16) | 32768] + lits[:50], np.uint32)
+    e, stream, _ = O.encode_tokens(toks)
+    assert e == 0
+    nbytes = len(lits) + 3 + 50
+    eo, _, _ = O.decode(stream, header=False, nbytes=nbytes)
+    assert eo == errno.EINVAL
+    back, derr = batch.decode_blocks_host([stream], [nbytes])
+    assert derr[0] == errno.EINVAL
+    # the same stream with the legal neighbour 32767 decodes (and is what the encoder may emit)
+    toks[len(lits)] = 0x80000000 | (3 << 16) | 32767
+    e, stream, _ = O.encode_tokens(toks)
+    eo, want, _ = O.decode(stream, header=False, nbytes=nbytes)
+    assert e == 0 and eo == 0
+    back, derr = batch.decode_blocks_host([stream], [nbytes])
+    assert derr[0] == 0 and back[0] == want
+    # both land inside a read-ahead step too: many copies in a row, first bad one wins
+    toks = np.array(lits + [0x80000000 | (3 << 16) | 32767] * 40 + [0x80000000 | (3 << 16) | 32768] + lits[:9], np.uint32)
+    e, stream, _ = O.encode_tokens(toks)
+    nbytes = len(lits) + 3 * 41 + 9
+    assert e == 0 and O.decode(stream, header=False, nbytes=nbytes)[0] == errno.EINVAL
+    assert batch.decode_blocks_host([stream], [nbytes])[1][0] == errno.EINVAL
+
+
+def test_short_scratch_is_refused_per_block(sq, batch):
+    """sqz_hip_encode_blocks cannot see the device-resident offsets: a scratch that does not
+    cover in_off[n] must fail the blocks beyond it with EINVAL, not write out of bounds"""
+    import torch
+    from sqz_amd import _native as N
+    n, bb = 8, 4096
+    d_in = batch.zipf_blocks(n, bb)
+    off = batch.uniform_offsets(n, bb)
+    enc = batch.Encoder(n, n * bb, sq.bound(bb))
+    L = N.lib()
+    short = int(L.sqz_hip_encode_scratch_bytes(n, 5 * bb))      # room for 5 of the 8 blocks
+    guard = torch.full((enc.scratch_bytes - short,), 0xA5, dtype=torch.uint8, device="cuda")
+    enc.scratch[short:] = guard
+    P = lambda t: C.c_void_p(t.data_ptr())
+    rc = L.sqz_hip_encode_blocks(P(d_in), P(off), n, 1 << 12, P(enc.out), P(enc.out_off), P(enc.out_bytes),
+                                 P(enc.err), P(enc.scratch), short, None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    err = enc.err.tolist()
+    assert err[:5] == [0] * 5 and err[5:] == [errno.EINVAL] * 3
+    assert enc.out_bytes[5:].tolist() == [0, 0, 0]
+    assert torch.equal(enc.scratch[short:], guard)              # nothing written past the scratch
+    for b in range(5):
+        got = enc.out[int(enc.out_off[b]):int(enc.out_off[b]) + int(enc.out_bytes[b])].cpu().numpy().tobytes()
+        assert got == O.encode(O.zipf_block(b, bb), 12, header=False)
+    for bad in ("d_out", "d_out_off", "d_out_bytes", "d_err"):   # NULL pointers are EINVAL, not a fault
+        a = dict(d_out=P(enc.out), d_out_off=P(enc.out_off), d_out_bytes=P(enc.out_bytes), d_err=P(enc.err))
+        a[bad] = None
+        assert L.sqz_hip_encode_blocks(P(d_in), P(off), n, 1 << 12, a["d_out"], a["d_out_off"], a["d_out_bytes"],
+                                       a["d_err"], P(enc.scratch), enc.scratch_bytes, None) == errno.EINVAL

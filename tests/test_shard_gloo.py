@@ -50,6 +50,12 @@ def _worker(rank, world, port, q):
         slabs[k * SLAB:k * SLAB + len(comp)] = torch.tensor(np.frombuffer(comp, np.uint8).copy())
         sizes[k] = len(comp)
     all_slabs, all_sizes = shard.gather_slabs(slabs, sizes, N_BLOCKS, SLAB, dev)
+    # the dense flavour (what bench.py ships): streams back to back, 8-byte aligned starts
+    off = shard.dense_offsets(sizes)
+    dense = torch.zeros(int(off[-1]), dtype=torch.uint8)
+    for k in range(hi - lo):
+        dense[int(off[k]):int(off[k]) + int(sizes[k])] = slabs[k * SLAB:k * SLAB + int(sizes[k])]
+    g_dense, g_sizes, g_off = shard.gather_dense(dense, sizes, N_BLOCKS, dev)
     slowest = shard.max_over_ranks(1.0 + rank, dev)
     total = shard.sum_over_ranks(float(sizes.sum()), dev)
     assert slowest == float(world)
@@ -58,9 +64,12 @@ def _worker(rank, world, port, q):
         for b in range(N_BLOCKS):
             n = int(all_sizes[b])
             got.append(all_slabs[b * SLAB:b * SLAB + n].numpy().tobytes())
+        assert torch.equal(g_sizes, all_sizes) and int(g_off[-1]) == g_dense.numel()
+        got2 = [g_dense[int(g_off[b]):int(g_off[b]) + int(g_sizes[b])].numpy().tobytes() for b in range(N_BLOCKS)]
+        assert got2 == got
         q.put((got, total))
     else:
-        assert all_slabs is None
+        assert all_slabs is None and g_dense is None
     dist.barrier()
     dist.destroy_process_group()
 

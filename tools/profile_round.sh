@@ -1,10 +1,13 @@
 #!/bin/bash
 # the judged measurement set: bench line, rocprofv3 kernel stats of the same command,
-# and HBM traffic (FETCH_SIZE / WRITE_SIZE in their own PMC passes, kernel trace only)
+# and HBM traffic (FETCH_SIZE / WRITE_SIZE in their own PMC passes, kernel trace only).
+# Writes gpurun_out/prof_$PROF_TAG/{bench_line.json,kernel_stats.csv,pmc_hbm.json,traffic_current.json};
+# copy them into profiles/ (traffic_current.json -> the "current" slot of profiles/traffic.json:
+# tools/adopt_profile.py does that) and commit.
 set -o pipefail
 export TMPDIR=/tmp
 R=$PWD
-export PROF_TAG=${PROF_TAG:-v4}
+export PROF_TAG=${PROF_TAG:-r02}
 O=$R/gpurun_out/prof_$PROF_TAG
 mkdir -p $O
 timeout -k 10 300 python bench.py --steps 2 --warmup 1 > $O/bench.log 2>&1 || { tail -5 $O/bench.log; exit 1; }
@@ -17,7 +20,9 @@ done
 cd $R
 find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 python - <<'PY'
-import csv, glob, collections, json, os
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
 O = "gpurun_out/prof_" + os.environ["PROF_TAG"]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -30,7 +35,24 @@ for f in glob.glob(O + "/*SIZE/**/*counter_collection.csv", recursive=True):
 out = {k: {"fetch_kib_raw": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"),
            "launches": len(n[k].get("FETCH_SIZE", ()))} for k, v in acc.items()}
 json.dump(out, open(O + "/pmc_hbm.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+# MI355X_MICROARCH.md (HBM / rocprofv3): counters are KiB; on gfx950 FETCH_SIZE reports half the
+# bytes of a wide (16 B per lane) coalesced streaming read and is doubled for those; WRITE_SIZE is
+# exact.  Which kernels stream 16 B per lane is a property of the code: none of the current ones do
+# for the bulk of their reads (dword / byte gathers, 4 B per lane), so FETCH_SIZE is taken as is
+# and the doubled figure is kept beside it as the upper bound.
+cur = {"kernel_build_id": bench.kernel_build_id(),
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only) of "
+                 "`python bench.py --steps 1 --warmup 0 --cpu-blocks 0 --no-verify`; KiB -> bytes; per launch; "
+                 "FETCH_SIZE not doubled (no 16-B-per-lane streaming reads in these kernels; doubled figure "
+                 "listed as hbm_bytes_per_launch_if_fetch_doubled), WRITE_SIZE exact (MI355X_MICROARCH.md, HBM section)",
+       "kernels": {}}
+for k, v in out.items():
+    l = max(v["launches"], 1)
+    f, w = (v["fetch_kib_raw"] or 0.0) * 1024 / l, (v["write_kib"] or 0.0) * 1024 / l
+    cur["kernels"][k] = {"fetch_bytes": int(f), "write_bytes": int(w), "hbm_bytes_per_launch": int(f + w),
+                         "hbm_bytes_per_launch_if_fetch_doubled": int(2 * f + w)}
+json.dump(cur, open(O + "/traffic_current.json", "w"), indent=1)
+print(json.dumps(cur, indent=1))
 print(open(O + "/bench_line.json").read()[:600])
 PY
 head -8 $O/kernel_stats.csv | cut -c1-160
