@@ -70,10 +70,10 @@ def test_scatter_hip_encode_gather_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
+    streams, total, derr, same = q.get()        # before the joins: a full pipe would block rank 0's put
     for p in procs:
-        p.join(500)
+        p.join(300)
         assert p.exitcode == 0
-    streams, total, derr, same = q.get()
     want = [O.encode(O.zipf_block(b, BLOCK), WB, header=False) for b in range(N_BLOCKS)]
     assert streams == want                      # every gathered stream is the oracle's, in block order
     assert total == float(sum(len(w) for w in want))

@@ -10,6 +10,7 @@ mkdir -p $O
 for n in 512 1024 2048 4096; do
   timeout -k 10 200 python bench.py --steps 3 --warmup 1 --blocks $n --cpu-blocks 0 > $O/b$n.log 2>&1 || { tail -5 $O/b$n.log; exit 1; }
   grep '^{' $O/b$n.log > $O/blocks_$n.json
+  echo "blocks $n done"
 done
 SQZ_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
   --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --blocks 1024 > $O/n2.log 2>&1 || { tail -20 $O/n2.log; exit 1; }
