@@ -224,6 +224,49 @@ SQZ_API int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_i
                                    uint64_t* d_out_bytes, int32_t* d_err,
                                    void* stream);
 
+/* Counters the reference keeps next to the hot path, per block, opt-in:
+ *   huffman.h:29-33   stats.updates (huffman_update_paths calls, one per node visited, :42),
+ *                     stats.swaps (:76), stats.moves (:111), for each tree
+ *   squeeze.h:327-328,386,391  li_bytes / br_bytes: source bytes coded as literals / as back
+ *                     references (what SQUEEZE_MAP_STATS prints as percentages, :397-403)
+ *   huffman.h:26      the depth marks at the end;  huffman.h:237-249 huffman_entropy is
+ *                     sqz_stats_entropy() over the leaf counts returned here
+ * Pass a device array of n entries to sqz_hip_encode_blocks_stats (NULL = no counters).
+ * The update counter follows the reference while a tree is shallower than 26 levels (any
+ * stream of less than 2^25 symbols); deeper trees keep swaps / moves only.                  */
+typedef struct sqz_block_stats {
+    uint32_t lit_updates, lit_swaps, lit_moves;
+    uint32_t pos_updates, pos_swaps, pos_moves;
+    uint32_t literal_bytes, backref_bytes;
+    uint32_t lit_depth, pos_depth;
+    uint32_t tokens, reserved;
+    uint32_t lit_freq[288];      /* count of every leaf of the literal/length tree (symbol = index) */
+    uint32_t pos_freq[32];       /* ... of the distance tree */
+} sqz_block_stats;
+SQZ_API int sqz_hip_encode_blocks_stats(const void* d_in, const uint64_t* d_in_off, uint32_t n,
+                                        uint32_t window,
+                                        void* d_out, const uint64_t* d_out_off,
+                                        uint64_t* d_out_bytes, int32_t* d_err,
+                                        void* d_scratch, uint64_t scratch_bytes,
+                                        sqz_block_stats* d_stats, void* stream);
+/* huffman.h:237-249: Shannon entropy (bits per symbol) of `n` leaf counts.  Host arithmetic. */
+SQZ_API double sqz_stats_entropy(const uint32_t* freq, uint32_t n);
+
+/* Test entry: drive ONE adaptive Huffman tree on the device with a symbol sequence through
+ * huffman_inc_frequency semantics (huffman.h:218-235; unseen symbol -> huffman_insert :149) --
+ * exactly the code paths the encoder uses: runs of attached symbols in batches of `batch`
+ * (1..64) through the batched update, everything else one at a time -- and dump its node arrays.
+ * which: 0 = the literal/length tree (n = 512 in the reference, 288 leaf ids here), 1 = the
+ * distance tree (n = 32).  d_dump: 8 + 4 * nodes uint32 (nodes = 576 / 64):
+ *   [0..7]  next id, depth mark (huffman.h:26), complete (:27), intervals kept, fault,
+ *           stats.updates, stats.swaps, stats.moves (huffman.h:29-33)
+ *   then per node id v:  up | lo << 10 | hi << 20 (0x3FF = none; ids are absolute: + 576 for the
+ *           distance tree),  st | en << 9 | partner << 18,  count | depth << 24,  code (leaves)
+ * Leaves keep their symbol value as id, the root is id `leaves`, internal nodes count up from it
+ * (the reference counts down from 2n-2; no emitted bit depends on the numbering).           */
+SQZ_API int sqz_hip_debug_tree(const int32_t* d_symbols, uint32_t count, int which, int batch,
+                               uint32_t* d_dump, void* stream);
+
 /* Streams of a batch, back to back: stream b moves from d_slabs + d_slab_off[b] (where
  * sqz_hip_encode_blocks left it) to d_dense + d_dense_off[b]; d_dense_off = exclusive prefix
  * sum of d_bytes, every entry a multiple of 8 (n + 1 entries, computed by the caller on the device).  The dense image with

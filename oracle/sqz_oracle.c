@@ -693,6 +693,21 @@ int sqzo_tree_run(int32_t n, const int32_t* symbols, uint64_t count,
     return 0;
 }
 
+/* the same drive, returning only huffman.h:29-33's counters: updates, swaps, moves */
+int sqzo_tree_counters(int32_t n, const int32_t* symbols, uint64_t count, uint64_t out[3]) {
+    if (n < 8 || n > MAX_LEAVES || (n & (n - 1)) != 0) { return EINVAL; }
+    tree* t = (tree*)malloc(sizeof(tree));
+    if (t == NULL) { return ENOMEM; }
+    tree_init(t, n);
+    for (uint64_t k = 0; k < count; k++) {
+        if (symbols[k] < 0 || symbols[k] >= n) { free(t); return EINVAL; }
+        tree_bump(t, symbols[k]);
+    }
+    out[0] = t->st_updates; out[1] = t->st_swaps; out[2] = t->st_moves;
+    free(t);
+    return 0;
+}
+
 uint64_t sqzo_fnv1a64(const uint8_t* p, uint64_t n) {
     uint64_t h = 0xcbf29ce484222325ULL;
     for (uint64_t i = 0; i < n; i++) { h = (h ^ p[i]) * 0x100000001b3ULL; }

@@ -32,6 +32,13 @@ KERNEL_NAMES = ["lz77_scan_kernel", "huffman_emit_kernel", "entropy_decode_kerne
                 "lz_expand_kernel", "reserved"]
 
 
+class BlockStats(C.Structure):
+    """sqz_block_stats: the reference's counters per block (huffman.h:29-33, squeeze.h:397-403)."""
+    _fields_ = [(n, C.c_uint32) for n in ("lit_updates lit_swaps lit_moves pos_updates pos_swaps pos_moves "
+                                          "literal_bytes backref_bytes lit_depth pos_depth tokens reserved").split()] + \
+               [("lit_freq", C.c_uint32 * 288), ("pos_freq", C.c_uint32 * 32)]
+
+
 class Timing(C.Structure):
     """sqz_hip_timing: per-kernel summed durations (HIP events on the launch stream)."""
     _fields_ = [("ms", C.c_float * 8), ("launches", C.c_uint32 * 8)]
@@ -73,12 +80,16 @@ PROTOTYPES = {
     "sqz_hip_encode_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
     "sqz_hip_encode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
                                         _vp, C.c_uint64, _vp]),
+    "sqz_hip_encode_blocks_stats": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
+                                              _vp, C.c_uint64, _vp, _vp]),
+    "sqz_stats_entropy": (C.c_double, [_vp, C.c_uint32]),
     "sqz_hip_decode_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
     "sqz_hip_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "sqz_hip_lz77_blocks": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "sqz_hip_lz77_blocks_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int, _vp,
                                          C.c_uint64, _vp]),
     "sqz_hip_huffman_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sqz_hip_debug_tree": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp]),
     "sqz_hip_pack_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
     "sqz_hip_set_finder": (None, [C.c_int]),
     "sqz_hip_get_finder": (C.c_int, []),

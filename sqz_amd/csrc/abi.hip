@@ -8,6 +8,7 @@
 #include "sqz_kernels.h"
 
 #include <errno.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -267,11 +268,11 @@ void run_encode(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
                 uint32_t window, uint32_t* tokens, uint32_t* counts, uint32_t* work_a,
                 uint32_t* work_m, uint64_t avg_block, uint8_t* d_out, const uint64_t* d_out_off,
                 uint64_t* d_out_bytes, int32_t* d_err, uint64_t prefix_acc, int prefix_fill,
-                uint64_t slots, hipStream_t st) {
+                uint64_t slots, sqz_block_stats* d_stats, hipStream_t st) {
     run_stage1(finder, d_in, d_in_off, n, window, tokens, counts, work_a, work_m, avg_block, slots, st);
     SpanGuard g(st, SQZ_HIP_K_HUFFMAN_EMIT);
     sqzk::launch_huffman_emit(tokens, d_in_off, counts, d_out, d_out_off, d_out_bytes, d_err, n,
-                              prefix_acc, prefix_fill, st);
+                              prefix_acc, prefix_fill, d_stats, st);
 }
 
 // host-buffer encode of n blocks; prefix = pending header bits of block 0
@@ -302,7 +303,7 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     run_encode(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
                (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
                (uint32_t*)c.work_m.p, widest, (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
-               (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, total_in + 64, st);
+               (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, total_in + 64, nullptr, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_bytes, c.out_bytes.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(err, c.err.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -715,13 +716,34 @@ int sqz_hip_huffman_blocks(const uint32_t* d_tokens, const uint64_t* d_in_off,
     if (e != 0) { return e; }
     SpanGuard g((hipStream_t)stream, SQZ_HIP_K_HUFFMAN_EMIT);
     sqzk::launch_huffman_emit(d_tokens, d_in_off, d_token_count, (uint8_t*)d_out, d_out_off,
-                             d_out_bytes, d_err, n, 0, 0, (hipStream_t)stream);
+                             d_out_bytes, d_err, n, 0, 0, nullptr, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
 int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
                           void* d_out, const uint64_t* d_out_off, uint64_t* d_out_bytes,
                           int32_t* d_err, void* d_scratch, uint64_t scratch_bytes, void* stream) {
+    return sqz_hip_encode_blocks_stats(d_in, d_in_off, n, window, d_out, d_out_off, d_out_bytes, d_err,
+                                       d_scratch, scratch_bytes, NULL, stream);
+}
+
+double sqz_stats_entropy(const uint32_t* freq, uint32_t n) {          // huffman.h:237-249
+    if (freq == NULL) { return 0.0; }
+    double total = 0.0, e = 0.0;
+    for (uint32_t i = 0; i < n; i++) { total += (double)freq[i]; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (freq[i] > 0) {
+            const double p = (double)freq[i] / total;
+            e += p * log2(p);
+        }
+    }
+    return -e;
+}
+
+int sqz_hip_encode_blocks_stats(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
+                                void* d_out, const uint64_t* d_out_off, uint64_t* d_out_bytes,
+                                int32_t* d_err, void* d_scratch, uint64_t scratch_bytes,
+                                sqz_block_stats* d_stats, void* stream) {
     if (n == 0) { return 0; }
     if (d_scratch == NULL || scratch_bytes < sqz_hip_encode_scratch_bytes(n, 0)) { return EINVAL; }
     if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL ||
@@ -740,7 +762,7 @@ int sqz_hip_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     uint32_t* work_m = work_a + slots;
     run_encode(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
                work_a, work_m, slots / n, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, 0, 0,
-               slots, (hipStream_t)stream);
+               slots, d_stats, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
@@ -765,6 +787,15 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
                                   nullptr, n, 0, (hipStream_t)stream); }
     { SpanGuard g((hipStream_t)stream, SQZ_HIP_K_LZ_EXPAND);
       sqzk::launch_lz_expand(tokens, counts, (uint8_t*)d_out, d_out_off, n, (hipStream_t)stream); }
+    return hip_errno(hipGetLastError());
+}
+
+int sqz_hip_debug_tree(const int32_t* d_symbols, uint32_t count, int which, int batch,
+                       uint32_t* d_dump, void* stream) {
+    if (d_symbols == NULL || d_dump == NULL || (which != 0 && which != 1)) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    sqzk::launch_tree_debug(d_symbols, count, which, batch, d_dump, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 

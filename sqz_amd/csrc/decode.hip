@@ -21,19 +21,28 @@
 // child, a raw symbol that is out of range or already in the tree, a distance
 // reaching before the stream start and a match running past the stream end
 // are EINVAL; reading past the compressed bytes is E2BIG (bitstream.h:74).
-#include "sqz_device.h"
+#include "sqz_tree.h"
 #include "sqz_kernels.h"
 
 namespace sqzk {
 
 constexpr int kStageDw = 128;          // staged stream dwords (big-endian values): 4096 bits
 
+struct DecodeLuts {
+    uint16_t lit[1 << 8];
+    uint16_t pos[1 << 6];
+};
+
 struct DecodeLds {
-    EntropyLds entropy;
+    TreeLds    tree;                    // tree.P32[0 .. 128) doubles as the read-ahead's token slots
+                                        // (word | (bits used - 1) << 25): they are in registers
+                                        // before the batched update needs the space
     DecodeLuts luts;
     uint32_t   stage[kStageDw];
-    uint32_t   slot[2 * kWave];         // read-ahead tokens: word | (bits used - 1) << 25
 };
+
+using LitTree = LitTreeT<false>;
+using PosTree = PosTreeT<false>;
 
 // squeeze.h:429-442; returns the leaf or -1 with err set.  The first 8 levels
 // of the root->leaf walk come from the lookup table (rebuilt whenever the tree
@@ -49,8 +58,8 @@ __device__ __forceinline__ int read_symbol(BitSource& r, T& t, int lane, int& er
     int d = (int)(e >> 10);
     while (node >= (int)T::kRoot && node != (int)kNil) {           // deeper than 8 levels
         r.fill();
-        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 32);     // lo | hi << 10
-        node = (int)((kids >> (r.peek(1) ? 10 : 0)) & 0x3FFu);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lds->lnk[node]);
+        node = (int)(r.peek(1) ? l_hi(w) : l_lo(w));
         r.skip(1);
         if (++d > 2 * kStack) { node = (int)kNil; }
     }
@@ -72,8 +81,8 @@ __device__ __forceinline__ int peek_symbol(BitSource& r, const T& t) {
     int d = (int)(e >> 10);
     while (node >= (int)T::kRoot && node != (int)kNil) {           // deeper than 8 levels
         r.fill();
-        const uint32_t kids = (uint32_t)(uni64(t.link[node]) >> 32);
-        node = (int)((kids >> (r.peek(1) ? 10 : 0)) & 0x3FFu);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lds->lnk[node]);
+        node = (int)(r.peek(1) ? l_hi(w) : l_lo(w));
         r.skip(1);
         if (++d > 2 * kStack) { node = (int)kNil; }
     }
@@ -103,9 +112,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     if (b >= n_blocks) { return; }
 
     LitTree lit; PosTree pos;
-    bind(lit, pos, &lds.entropy);
-    lit.lut = lds.luts.lit;
-    pos.lut = lds.luts.pos;
+    lit.lds = &lds.tree; lit.code = nullptr; lit.lut = lds.luts.lit;
+    pos.lds = &lds.tree; pos.code = nullptr; pos.lut = lds.luts.pos;
     lit.init_all(lane);
     pos.init_all(lane);
     __syncthreads();
@@ -121,10 +129,10 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     r.open(src, src_bytes, start_bit, lane);
     int err = 0;
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
-    if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
+    if (!pos.insert_wave(kPosBase + kPosNyt, lane)) { err = kEINVAL; }
 
-    uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
-    uint32_t* const freq = lds.entropy.lit_freq;
+    const uint32_t* const lnk = lds.tree.lnk;          // both trees: absolute node ids
+    uint32_t* const slot = lds.tree.P32;
     uint64_t i = 0;
     uint32_t ntok = 0;
 
@@ -155,13 +163,14 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             if (len < kLenMin || len > kLenMax) { err = kEINVAL; return; }
             int pk = read_symbol(r, pos, lane, err);                   // squeeze.h:476-500
             if (err != 0) { return; }
+            pk -= kPosBase;                                             // leaf id -> distance code
             if (pk == kPosNyt) {
                 pk = (int)r.get_lsb(5);
                 if (r.overrun()) { err = kE2BIG; return; }
                 if (pk >= kPosNyt) { err = kEINVAL; return; }
-                const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos.up_of(pk));
+                const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos.up_of(kPosBase + pk));
                 if (up != kNil) { err = kEINVAL; return; }
-                if (!pos.insert_wave(pk, lane)) { err = kE2BIG; return; }
+                if (!pos.insert_wave(kPosBase + pk, lane)) { err = kE2BIG; return; }
             }
             pos_base_of(pk, base, xb);
             int dist = base;
@@ -207,8 +216,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 else { __builtin_amdgcn_s_setprio(0); }
             }
         }
-        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
-                            ntok > (1u << 24) - 256u;
+        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
+                            (lit.aux & pos.aux) == 0 || ntok > (1u << 24) - 256u;
         if (lit.lut_ok == 0) { lit.build_lut(lane); }
         if (pos.lut_ok == 0) { pos.build_lut(lane); }
         // ---- read ahead with the trees held still: every lane decodes the token that would
@@ -247,8 +256,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 const bool more = node >= (uint32_t)kLitLeaves && node != kNil;
                 if (__ballot(more) == 0) { break; }
                 if (more) {
-                    const uint32_t kids = (uint32_t)(link[node] >> 32);
-                    node = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
+                    const uint32_t kw = lnk[node];
+                    node = (w >> 63) ? l_hi(kw) : l_lo(kw);
                     w <<= 1;
                     used++;
                 }
@@ -267,21 +276,21 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             w <<= xb;
             uint32_t more_bits = (uint32_t)xb;
             const uint32_t e2 = lds.luts.pos[(uint32_t)(w >> (64 - PosTree::kLutBits))];
-            uint32_t n2 = e2 & 0x3FFu;
+            uint32_t n2 = e2 & 0x3FFu;                               // absolute node id (or nil)
             w <<= (e2 >> 10);
             more_bits += e2 >> 10;
             for (int it = 0; it < 56; it++) {                      // deeper than the table
-                const bool more = is_len && n2 >= (uint32_t)kPosLeaves && n2 != kNil;
+                const bool more = is_len && n2 >= (uint32_t)PosTree::kRoot && n2 != kNil;
                 if (__ballot(more) == 0) { break; }
-                const uint32_t kids = (uint32_t)(link[kLitNodes + (more ? (int)n2 : (int)kPosLeaves)] >> 32);
-                const uint32_t down = (kids >> ((w >> 63) ? 10 : 0)) & 0x3FFu;
+                const uint32_t kw = lnk[more ? (int)n2 : (int)PosTree::kRoot];
+                const uint32_t down = (w >> 63) ? l_hi(kw) : l_lo(kw);
                 n2 = more ? down : n2;
                 w <<= more ? 1 : 0;
                 more_bits += more ? 1u : 0u;
             }
-            const bool pos_bad = n2 >= (uint32_t)kPosLeaves;      // nil / still inside
-            const bool pos_esc = n2 == (uint32_t)kPosNyt;
-            pos_base_of(pos_bad ? 0 : (int)n2, bs, xb);
+            const bool pos_bad = n2 >= (uint32_t)PosTree::kRoot;  // nil / still inside
+            const bool pos_esc = n2 == (uint32_t)(kPosBase + kPosNyt);
+            pos_base_of(pos_bad ? 0 : (int)n2 - kPosBase, bs, xb);
             const uint32_t dist = (uint32_t)bs + (__brev((uint32_t)(w >> 32)) & ((1u << xb) - 1u));
             more_bits += (uint32_t)xb;
             uint32_t word = node;
@@ -316,7 +325,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             if ((starts >> lane) & 1ull) {
                 const int at = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32),
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
-                lds.slot[at] = word | ((used - 1u) << 25);
+                slot[at] = word | ((used - 1u) << 25);
             }
             m += __builtin_popcountll(starts);
             ST_SEC(1)
@@ -326,7 +335,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // ---- lane j = token j: positions, validity, symbols ---------------------------------
         uint32_t word_v = 0, used_v = 0;
-        if (lane < m) { const uint32_t sl = lds.slot[lane]; word_v = sl & 0x81FFFFFFu; used_v = ((sl >> 25) & 63u) + 1u; }
+        if (lane < m) { const uint32_t sl = slot[lane]; word_v = sl & 0x81FFFFFFu; used_v = ((sl >> 25) & 63u) + 1u; }
         const bool is_match = (word_v & kTokMatch) != 0;
         const uint32_t tlen_v = lane < m ? (is_match ? ((word_v >> 16) & 0x1FFu) : 1u) : 0u;
         uint32_t scan = (used_v << 16) | tlen_v;               // both sums fit 16 bits
@@ -341,17 +350,18 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         if (lane < m) {
             if (is_match) {
                 a_v = kSymLen0 + len_code((int)tlen_v).code;
-                b_v = kLitNodes + pos_code((int)(word_v & 0x7FFFu)).code;
+                b_v = kPosBase + pos_code((int)(word_v & 0x7FFFu)).code;
             } else {
                 a_v = (int)word_v;
             }
         }
         // ---- apply the longest prefix that changes no link ------------------------------------
-        uint64_t ca, cb;
+        uint32_t ca, cb;
         int wa, wb;
         int done = 0;
         ST_SEC(2)
-        if (m > 0) { done = bump_lanes<false>(link, freq, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        lds_fence();                                          // the slots are in registers: their space is the batch's now
+        if (m > 0) { done = bump_batch<false>(&lds.tree, nullptr, lit, pos, lane, m, a_v, b_v, ca, wa, cb, wb); }
         ST_SEC(3)
         uint64_t resume = bit0;
         if (done > 0) {
@@ -391,7 +401,6 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         printf("cycles total %llu: round %llu hop+slot %llu post %llu bump %llu store %llu exact %llu\n", (unsigned long long)(st_last - st_begin),
                (unsigned long long)st_sec[0], (unsigned long long)st_sec[1], (unsigned long long)st_sec[2], (unsigned long long)st_sec[3], (unsigned long long)st_sec[4], (unsigned long long)st_sec[5]);
         printf("round parts: stage+window %llu lit lut+deep %llu match %llu\n", (unsigned long long)st_sec[6], (unsigned long long)st_sec[7], (unsigned long long)st_sec[0]);
-        printf("bump: open %llu count %llu mid %llu add %llu count-iters %llu\n", g_st[0], g_st[1], g_st[2], g_st[3], g_st[4]);
         printf("lit slow: insert %u/%llu changed %u/%llu lut %u/%llu; pos: insert %u/%llu changed %u/%llu lut %u/%llu\n",
                lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1], lit.st_cnt[2], (unsigned long long)lit.st_cyc[2],
                pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1], pos.st_cnt[2], (unsigned long long)pos.st_cyc[2]);

@@ -8,35 +8,38 @@
 //   squeeze.h:239-246 squeeze_write_huffman    (code from the tree BEFORE the
 //                                               frequency update)
 //   squeeze.h:248-253 squeeze_flush, bitstream.h:28-63 (MSB-first words)
-// The wave runs uniformly.  Up to 64 tokens per step, one per lane: every lane walks the
-// leaf->root chains of its token's symbols, reads the code off the chain and takes part in the
-// batched frequency update of sqz_device.h (bump_lanes); the tokens in front of the first lane
-// whose update could restructure a tree are applied and their bits -- code, extra bits, code,
-// extra bits, concatenated per lane -- are packed in parallel (prefix sum of the widths, LDS
-// atomic OR into a bit image) and leave as whole 8-byte words, coalesced.  The token a step
-// stops at (a restructure, an unseen symbol with its NYT escape) takes the one-at-a-time path:
-// lane k = level k of the chain, code = one __ballot("am I the hi child?"), the reference's
-// own swap / promote tests, restructuring on the whole wave; its bits wait in a register and
-// ride along with the next batch's pack.
-#include "sqz_device.h"
+// The wave runs uniformly.  Up to 64 tokens per step, one per lane: a lane looks its token's
+// symbols up (leaf position, code, depth: three LDS reads per symbol, no chain walk) and takes
+// part in the batched frequency update of sqz_tree.h (bump_batch); the tokens in front of the
+// first one whose update could restructure a tree are applied and their bits -- code, extra bits,
+// code, extra bits -- are packed in parallel (prefix sum of the widths, LDS atomic OR into a bit
+// image) and leave as whole 8-byte words, coalesced.  The token a step stops at (a restructure,
+// an unseen symbol with its NYT escape) takes the one-at-a-time path: lane k = level k of the
+// chain, code = one __ballot("am I the hi child?"), the reference's own swap / promote tests,
+// restructuring on the whole wave; its bits wait in a register and ride along with the next
+// batch's pack.
+#include "sqz_tree.h"
 #include "sqz_kernels.h"
 
 namespace sqzk {
 
-constexpr int kImageWords = 62;       // carry + pending + 64 lanes x <= 58 bits
-constexpr int kLaneBits = 58;         // most bits one lane (or the pending register) hands to a pack
+constexpr int kPendBits = 58;         // most bits the pending register hands to a pack
 
 struct EmitLds {
-    EntropyLds entropy;
-    uint64_t   image[kImageWords];    // packed bits of one batch, stream order = MSB first
+    TreeLds  tree;                    // tree.P64 doubles as the bit image of a pack (stream order = MSB first)
+    uint32_t code[kCodeSlots];
 };
+
+using LitTree = LitTreeT<true>;
+using PosTree = PosTreeT<true>;
 
 struct BitQueue {
     EmitLds* lds;
     uint8_t* out;        // global
     uint64_t capacity;
     uint64_t bytes;      // bytes produced so far (as the reference counts them)
-    int      carry;      // bits already sitting in image[0] (0..63)
+    uint64_t carry_v;    // the bits of the last partial word, left-aligned (what image[0] starts as)
+    int      carry;      // how many (0..63)
     int      error;
     // bits of the one-at-a-time path waiting for the next pack: the low pend_n bits of pend_v,
     // first-out bit on top.  They ride along with the next batch instead of costing a pack of
@@ -48,14 +51,14 @@ struct BitQueue {
     __device__ __forceinline__ void store_words(int words, int lane) {
         if (error != 0 || words == 0) { return; }
         const uint64_t room = capacity - bytes;
-        if (lane < words) {
-            const uint64_t w = lds->image[lane];
-            const uint64_t at = (uint64_t)lane * 8;
+        for (int k = lane; k < words; k += kWave) {
+            const uint64_t w = lds->tree.P64[k];
+            const uint64_t at = (uint64_t)k * 8;
             if (at + 8 <= room) {
                 *reinterpret_cast<uint64_t*>(out + bytes + at) = __builtin_bswap64(w);
             } else {
-                for (int k = 0; k < 8; k++) {              // byte by byte up to the capacity
-                    if (at + (uint64_t)k < room) { out[bytes + at + k] = (uint8_t)(w >> (56 - 8 * k)); }
+                for (int j = 0; j < 8; j++) {              // byte by byte up to the capacity
+                    if (at + (uint64_t)j < room) { out[bytes + at + j] = (uint8_t)(w >> (56 - 8 * j)); }
                 }
             }
         }
@@ -67,45 +70,47 @@ struct BitQueue {
     __device__ __forceinline__ void deposit(uint64_t v, uint32_t n, uint32_t o) {
         const uint32_t w = o >> 6, s = o & 63u;
         if (s + n <= 64) {
-            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->tree.P64[w]),
                      (unsigned long long)v << (64 - s - n));
         } else {
             const uint32_t r = s + n - 64;              // bits spilling into the next word
-            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w]),
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->tree.P64[w]),
                      (unsigned long long)(v >> r));
-            atomicOr(reinterpret_cast<unsigned long long*>(&lds->image[w + 1]),
+            atomicOr(reinterpret_cast<unsigned long long*>(&lds->tree.P64[w + 1]),
                      (unsigned long long)v << (64 - r));
         }
     }
 
-    // the pending bits, then every lane's `n` bits (0..58, first-out bit = most significant of
-    // v): prefix sum of the widths, LDS atomic OR into the image behind the carried bits, full
-    // words leave for HBM
-    __device__ __forceinline__ void pack_lanes(uint64_t v, uint32_t n, int lane) {
-        uint32_t incl = n;
-        incl = wave_scan(incl);
+    // the pending bits, then every lane's two fields (n1 then n2 bits, each 0..38, first-out bit =
+    // most significant): prefix sum of the widths, LDS atomic OR into the image behind the carried
+    // bits, full words leave for HBM
+    __device__ __forceinline__ void pack_lanes(uint64_t v1, uint32_t n1, uint64_t v2, uint32_t n2, int lane) {
+        for (int k = lane; k < kImageWords; k += kWave) { lds->tree.P64[k] = (k == 0) ? carry_v : 0ull; }
+        lds_fence();
+        const uint32_t incl = wave_scan(n1 + n2);
         const uint32_t head = (uint32_t)carry + (uint32_t)pend_n;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) + head;
         if (pend_n != 0 && lane == 0) { deposit(pend_v, (uint32_t)pend_n, (uint32_t)carry); }
-        if (n != 0) { deposit(v, n, head + incl - n); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t at = head + incl - (n1 + n2);
+        if (n1 != 0) { deposit(v1, n1, at); }
+        if (n2 != 0) { deposit(v2, n2, at + n1); }
+        lds_fence();
         const int words = (int)(total >> 6);
         store_words(words, lane);
-        const uint64_t rest = lds->image[words];           // partial word becomes the new carry
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane < kImageWords) { lds->image[lane] = (lane == 0) ? rest : 0ull; }
+        carry_v = uni64(lds->tree.P64[words]);             // partial word becomes the new carry
+        lds_fence();
         carry = (int)(total & 63u);
         pend_v = 0; pend_n = 0;
     }
 
     // what is pending, alone (the register is full, or the stream ends)
     __device__ __forceinline__ void pack(int lane) {
-        if (pend_n != 0) { pack_lanes(0ull, 0u, lane); }
+        if (pend_n != 0) { pack_lanes(0ull, 0u, 0ull, 0u, lane); }
     }
 
     // value's low `width` bits, first-out bit = most significant; width 1..32
     __device__ __forceinline__ void push32(uint32_t value, int width, int lane) {
-        if (pend_n + width > kLaneBits) { pack(lane); }
+        if (pend_n + width > kPendBits) { pack(lane); }
         const uint64_t bits = width >= 32 ? (uint64_t)value : (uint64_t)(value & ((1u << width) - 1u));
         pend_v = (pend_v << width) | bits;
         pend_n += width;
@@ -125,18 +130,24 @@ struct BitQueue {
 
     __device__ __forceinline__ void flush(int lane) {       // bitstream.h:112-114
         pack(lane);
-        if (carry > 0) { store_words(1, lane); carry = 0; }
+        if (carry > 0) {
+            if (lane == 0) { lds->tree.P64[0] = carry_v; }
+            lds_fence();
+            store_words(1, lane);
+            carry = 0; carry_v = 0;
+        }
     }
 };
 
-__device__ __noinline__ uint64_t deep_code(const uint64_t* link, int leaf, int& width) {
+// the code of a chain longer than the wave's ballot covers, by a walk (trees this deep need ~2^60 symbols)
+__device__ __noinline__ uint64_t deep_code(const uint32_t* lnk, int leaf, int& width) {
     uint64_t code = 0;
     int n = 0, a = leaf;
     for (;;) {
-        const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)link[a] & 0x3FFu));
+        const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_up(lnk[a]));
         if (up == kNil || n >= 63) { break; }
-        const Node pn = unpack(uni64(link[up]));
-        code |= (uint64_t)(pn.hi == (uint32_t)a ? 1 : 0) << n;
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnk[up]);
+        code |= (uint64_t)(l_hi(pw) == (uint32_t)a ? 1 : 0) << n;
         a = (int)up;
         n++;
     }
@@ -144,7 +155,7 @@ __device__ __noinline__ uint64_t deep_code(const uint64_t* link, int leaf, int& 
     return code;
 }
 
-// squeeze.h:278-288 / :300-315: symbol s through tree t with the NYT escape
+// squeeze.h:278-288 / :300-315: symbol s (a leaf id) through tree t with the NYT escape
 template <class T>
 __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, int raw_bits,
                                            int lane, int& err) {
@@ -154,10 +165,10 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
     const int leaf = unseen ? nyt : s;
     uint64_t code = t.bump_wave(leaf, c, lane);             // code of the tree BEFORE the update
     int width = c.levels;                                   // ballot bits beyond `levels` are 0
-    if (width >= kMaxFastDepth) { code = deep_code(t.link, leaf, width); }
+    if (width >= kMaxFastDepth) { code = deep_code(t.lds->lnk, leaf, width); }
     q.push(code, width, lane);
     if (unseen) {
-        q.push_lsb((uint32_t)s, raw_bits, lane);
+        q.push_lsb((uint32_t)(s - T::kBase), raw_bits, lane);
         if (!t.insert_wave(s, lane)) { err = kE2BIG; }
     }
 }
@@ -176,7 +187,7 @@ __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& p
     if (is_match) {
         if (lc.xbits > 0) { q.push_lsb((uint32_t)lc.extra, lc.xbits, lane); }
         const Code pc = pos_code((int)(t & 0x7FFFu));                 // squeeze.h:300-315
-        emit_coded(q, pos, pc.code, kPosNyt, 5, lane, err);
+        emit_coded(q, pos, kPosBase + pc.code, kPosBase + kPosNyt, 5, lane, err);
         if (pc.xbits > 0) { q.push_lsb((uint32_t)pc.extra, pc.xbits, lane); }
     }
     if (q.error != 0) { err = q.error; }
@@ -192,11 +203,10 @@ __device__ __forceinline__ bool token_ok(uint32_t t) {
     return len >= (uint32_t)kLenMin && len <= (uint32_t)kLenMax && dist >= 1u && dist <= 0x7FFFu;
 }
 
-// Tokens of stage 1 -> bit stream.  Up to 64 tokens per step, one per lane
-// (sqz_device.h: bump_lanes); a step shrinks to the tokens in front of the first unseen or
-// malformed one, then to the longest prefix that changes no link, and the token it stops at
-// (the tree really restructures, or it needs the NYT escape) goes through the one-at-a-time
-// path in the same step.
+// Tokens of stage 1 -> bit stream.  Up to 64 tokens per step, one per lane (sqz_tree.h:
+// bump_batch); a step shrinks to the tokens in front of the first unseen or malformed one, then to
+// the longest prefix that changes no link, and the token it stops at (the tree really
+// restructures, or it needs the NYT escape) goes through the one-at-a-time path in the same step.
 __global__ __launch_bounds__(kWave)
 void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                          const uint64_t* __restrict__ tok_off,
@@ -206,20 +216,19 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                          uint64_t* __restrict__ out_bytes,
                          int32_t* __restrict__ err_out,
                          uint32_t n_blocks,
-                         uint64_t prefix_acc, int prefix_fill) {
+                         uint64_t prefix_acc, int prefix_fill,
+                         sqz_block_stats* __restrict__ stats_out) {
     __shared__ EmitLds lds;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
 
     LitTree lit; PosTree pos;
-    bind(lit, pos, &lds.entropy);
+    lit.lds = &lds.tree; lit.code = lds.code; lit.lut = nullptr;
+    pos.lds = &lds.tree; pos.code = lds.code; pos.lut = nullptr;
     lit.init_all(lane);
     pos.init_all(lane);
-    if (lane < kImageWords) {
-        // header bits that precede the payload (single-stream API): the carry
-        lds.image[lane] = (lane == 0 && prefix_fill > 0) ? (prefix_acc << (64 - prefix_fill)) : 0ull;
-    }
+    for (int k = lane; k < kCodeSlots; k += kWave) { lds.code[k] = 0; }
     __syncthreads();
 
     const uint32_t* tok = tokens + uni64(tok_off[b]);
@@ -235,17 +244,18 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     q.bytes = 0;
     q.pend_v = 0;
     q.pend_n = 0;
+    // header bits that precede the payload (single-stream API): the carry
     q.carry = prefix_fill;
+    q.carry_v = prefix_fill > 0 ? (prefix_acc << (64 - prefix_fill)) : 0ull;
     q.error = 0;
     int err = 0;
 
     if (too_many) { err = kEINVAL; }
     if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:333-334
-    if (!pos.insert_wave(kPosNyt, lane)) { err = kEINVAL; }
+    if (!pos.insert_wave(kPosBase + kPosNyt, lane)) { err = kEINVAL; }
 
-    uint64_t* const link = lds.entropy.lit_link;      // both trees: pos ids + kLitNodes
-    uint32_t* const freq = lds.entropy.lit_freq;
     uint32_t cursor = 0;
+    uint32_t lit_tokens = 0, match_bytes = 0;         // squeeze.h:327-328 li_bytes / br_bytes
     // The tokens [cursor, cursor + 128) sit in two registers per lane.  After a step the window is
     // shifted by what the step consumed (two ds_bpermute) and its second half reloaded from memory:
     // that load is in flight during the whole next step instead of being waited for.
@@ -263,12 +273,12 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     int prio_now = -1;
     while (cursor < count && err == 0) {
         {
-            const int q = (int)(cursor / quarter);             // 0..3
-            if (q != prio_now) {
-                prio_now = q;
-                if (q == 0) { __builtin_amdgcn_s_setprio(3); }
-                else if (q == 1) { __builtin_amdgcn_s_setprio(2); }
-                else if (q == 2) { __builtin_amdgcn_s_setprio(1); }
+            const int qq = (int)(cursor / quarter);             // 0..3
+            if (qq != prio_now) {
+                prio_now = qq;
+                if (qq == 0) { __builtin_amdgcn_s_setprio(3); }
+                else if (qq == 1) { __builtin_amdgcn_s_setprio(2); }
+                else if (qq == 2) { __builtin_amdgcn_s_setprio(1); }
                 else { __builtin_amdgcn_s_setprio(0); }
             }
         }
@@ -281,40 +291,45 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         const bool is_match = (t & kTokMatch) != 0;
         Code lc = {0, 0, 0}, pc = {0, 0, 0};
         int a = (int)(t & 0xFFu), bsym = -1;
+        uint32_t tlen = 1;
         if (is_match) {
-            lc = len_code((int)((t >> 16) & 0x1FFu));                 // squeeze.h:290-298
-            pc = pos_code((int)(t & 0x7FFFu));                        // squeeze.h:300-315
+            tlen = (t >> 16) & 0x1FFu;
+            lc = len_code((int)tlen);                                  // squeeze.h:290-298
+            pc = pos_code((int)(t & 0x7FFFu));                         // squeeze.h:300-315
             a = kSymLen0 + lc.code;
-            bsym = kLitNodes + pc.code;
+            bsym = kPosBase + pc.code;
         }
         // unseen symbols need the NYT escape + an insert: they end the step
-        const uint32_t da = valid ? (uint32_t)(link[a] >> 52) & 0x3Fu : 1u;
-        const uint32_t db = (valid && is_match) ? (uint32_t)(link[bsym] >> 52) & 0x3Fu : 1u;
+        const uint32_t da = valid ? c_d(lds.tree.cnt[a]) : 1u;
+        const uint32_t db = (valid && is_match) ? c_d(lds.tree.cnt[bsym]) : 1u;
         const uint64_t unseen = __ballot(valid && (da == 0 || db == 0 || !wellformed));
         const uint64_t vmask = __ballot(valid);
         int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
-        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= 63 || pos.depth >= 63 ||
-                            cursor > (1u << 24) - 256u;
-        uint64_t ca = 0, cb = 0;
+        const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
+                            (lit.aux & pos.aux) == 0 || cursor > (1u << 24) - 256u;
+        uint32_t ca = 0, cb = 0;
         int wa = 0, wb = 0;
         const int offered = m;
         ES(0)
-        if (m >= 1 && !frozen) { m = bump_lanes<true>(link, freq, lane, m, a, bsym, ca, wa, cb, wb); }
+        if (m >= 1 && !frozen) { m = bump_batch<true>(&lds.tree, lds.code, lit, pos, lane, m, a, bsym, ca, wa, cb, wb); }
         else { m = 0; }
         ES(1)
         if (m >= 1) {
-            // this lane's bits: code [extra] [code extra], first-out bit on top
-            uint64_t v = ca;
-            uint32_t n = (uint32_t)wa;
+            // this lane's bits: code [extra] | code extra, first-out bit on top
+            uint64_t v1 = ca, v2 = 0;
+            uint32_t n1 = (uint32_t)wa, n2 = 0;
             if (is_match) {
-                v = (v << lc.xbits) | (uint64_t)(lc.xbits ? (__brev((uint32_t)lc.extra) >> (32 - lc.xbits)) : 0u);
-                v = (v << wb) | cb;
-                v = (v << pc.xbits) | (uint64_t)(pc.xbits ? (__brev((uint32_t)pc.extra) >> (32 - pc.xbits)) : 0u);
-                n += (uint32_t)(lc.xbits + wb + pc.xbits);
+                v1 = (v1 << lc.xbits) | (uint64_t)(lc.xbits ? (__brev((uint32_t)lc.extra) >> (32 - lc.xbits)) : 0u);
+                n1 += (uint32_t)lc.xbits;
+                v2 = ((uint64_t)cb << pc.xbits) | (uint64_t)(pc.xbits ? (__brev((uint32_t)pc.extra) >> (32 - pc.xbits)) : 0u);
+                n2 = (uint32_t)(wb + pc.xbits);
             }
-            if (lane >= m) { n = 0; v = 0; }
-            if (__ballot(n > 58) != 0) { err = kE2BIG; }               // codes this long never occur
-            q.pack_lanes(v, n, lane);                                  // what the last one-at-a-time token left goes first
+            if (lane >= m) { n1 = 0; n2 = 0; }
+            q.pack_lanes(v1, n1, v2, n2, lane);                        // what the last one-at-a-time token left goes first
+            // squeeze.h:386,391: source bytes coded as back references / as literals
+            const uint64_t mm = __ballot(lane < m && is_match);
+            lit_tokens += (uint32_t)(m - __builtin_popcountll(mm));
+            match_bytes += wave_sum((lane < m && is_match) ? tlen : 0u);
             cursor += (uint32_t)m;
         }
         ES(2)
@@ -324,6 +339,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)traw, m);
             if (!token_ok(tx)) { err = kEINVAL; break; }
             emit_token(q, lit, pos, tx, lane, err);
+            if ((tx & kTokMatch) != 0) { match_bytes += (tx >> 16) & 0x1FFu; } else { lit_tokens += 1; }
             cursor += 1;
 #ifdef SQZ_STATS
             es_exact++;
@@ -351,7 +367,9 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         printf("emit block 1: cycles %llu steps %u exact %u: prep %llu bump %llu pack %llu exact %llu\n",
                (unsigned long long)(es_last - es_begin), es_steps, es_exact, (unsigned long long)es[0],
                (unsigned long long)es[1], (unsigned long long)es[2], (unsigned long long)es[3]);
-        printf("emit bump: open %llu count %llu mid %llu add %llu count-iters %llu\n", g_st[0], g_st[1], g_st[2], g_st[3], g_st[4]);
+        printf("emit slow: lit insert %u/%llu changed %u/%llu; pos insert %u/%llu changed %u/%llu\n",
+               lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1],
+               pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1]);
     }
 #endif
     if (err == 0) { q.flush(lane); err = q.error; }
@@ -359,18 +377,111 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     if (lane == 0) {
         out_bytes[b] = q.bytes;
         err_out[b] = err;
+        if (stats_out != nullptr) {
+            sqz_block_stats st;
+            st.lit_updates = lit.stats.updates; st.lit_swaps = lit.stats.swaps; st.lit_moves = lit.stats.moves;
+            st.pos_updates = pos.stats.updates; st.pos_swaps = pos.stats.swaps; st.pos_moves = pos.stats.moves;
+            st.literal_bytes = lit_tokens; st.backref_bytes = match_bytes;
+            st.lit_depth = (uint32_t)lit.depth; st.pos_depth = (uint32_t)pos.depth;
+            st.tokens = cursor; st.reserved = 0;
+            stats_out[b] = st;
+        }
     }
+    // leaf counts for huffman_entropy (huffman.h:237-249; the host does the logarithms)
+    if (stats_out != nullptr) {
+        for (int k = lane; k < kLitLeaves; k += kWave) { stats_out[b].lit_freq[k] = c_f(lds.tree.cnt[k]); }
+        if (lane < kPosLeaves) { stats_out[b].pos_freq[lane] = c_f(lds.tree.cnt[kPosBase + lane]); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Debug / test entry: drive ONE tree with a symbol sequence exactly as the kernels above drive
+// it (batches of attached symbols through bump_batch, everything else one at a time through
+// chain_up / bump_wave / insert_wave) and dump its LDS image, so that the reference's tree dumps
+// (tests/golden/trees.npz, huffman.h node arrays) pin the device tree directly.
+// dump layout (uint32): [0..7] next, depth mark, complete, aux, fault, updates, swaps, moves;
+// then per node id v of the tree (NODES of them): lnk, rng, cnt, code (leaves; 0 otherwise).
+template <class T>
+__device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, EmitLds& lds, const int32_t* symbols,
+                                            uint32_t count, int batch, int lane, bool is_pos) {
+    uint32_t k = 0;
+    while (k < count) {
+        int sym = -1;
+        if (k + (uint32_t)lane < count) { sym = symbols[k + lane]; }
+        const bool valid = sym >= 0 && sym < T::kLeaves && lane < batch;
+        const int leaf = valid ? T::kBase + sym : T::kRoot;
+        const uint64_t seen = __ballot(valid && c_d(lds.tree.cnt[leaf]) != 0);
+        int m = __builtin_ctzll(~seen);                       // leading attached symbols (0..64)
+        const bool frozen = t.complete != 0 || t.depth >= kFreezeDepth || t.aux == 0;
+        uint32_t ca, cb; int wa, wb;
+        if (m > 0 && !frozen) {
+            m = is_pos ? bump_batch<true>(&lds.tree, lds.code, lit, pos, lane, m, -1, leaf, ca, wa, cb, wb)
+                       : bump_batch<true>(&lds.tree, lds.code, lit, pos, lane, m, leaf, -1, ca, wa, cb, wb);
+        } else { m = 0; }
+        k += (uint32_t)m;
+        if (k < count) {                                       // the symbol the batch stopped at, exactly
+            const int s = __builtin_amdgcn_readfirstlane(symbols[k]);
+            if (s < 0 || s >= T::kLeaves) { break; }
+            const int lf = T::kBase + s;
+            const Chain c = t.chain_up(lf, lane);
+            if (c.levels == 0) { (void)t.insert_wave(lf, lane); }
+            else { (void)t.bump_wave(lf, c, lane); }
+            k++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWave)
+void tree_debug_kernel(const int32_t* __restrict__ symbols, uint32_t count, int which, int batch,
+                       uint32_t* __restrict__ dump) {
+    __shared__ EmitLds lds;
+    const int lane = threadIdx.x;
+    LitTree lit; PosTree pos;
+    lit.lds = &lds.tree; lit.code = lds.code; lit.lut = nullptr;
+    pos.lds = &lds.tree; pos.code = lds.code; pos.lut = nullptr;
+    lit.init_all(lane);
+    pos.init_all(lane);
+    for (int k = lane; k < kCodeSlots; k += kWave) { lds.code[k] = 0; }
+    __syncthreads();
+    if (batch < 1) { batch = 1; }
+    if (batch > kWave) { batch = kWave; }
+    if (which == 0) { debug_drive(lit, lit, pos, lds, symbols, count, batch, lane, false); }
+    else { debug_drive(pos, lit, pos, lds, symbols, count, batch, lane, true); }
+    lds_fence();
+    const int base = which == 0 ? 0 : kPosBase, nodes = which == 0 ? kLitNodes : kPosNodes;
+    const int leaves = which == 0 ? kLitLeaves : kPosLeaves, pos0 = which == 0 ? 0 : kPosPos0;
+    if (lane == 0) {
+        const TreeStats st = which == 0 ? lit.stats : pos.stats;
+        dump[0] = (uint32_t)(which == 0 ? lit.next : pos.next);
+        dump[1] = (uint32_t)(which == 0 ? lit.depth : pos.depth);
+        dump[2] = (uint32_t)(which == 0 ? lit.complete : pos.complete);
+        dump[3] = (uint32_t)(which == 0 ? lit.aux : pos.aux);
+        dump[4] = (uint32_t)(which == 0 ? lit.fault : pos.fault);
+        dump[5] = st.updates; dump[6] = st.swaps; dump[7] = st.moves;
+    }
+    for (int v = lane; v < nodes; v += kWave) {
+        dump[8 + 4 * v + 0] = lds.tree.lnk[base + v];
+        dump[8 + 4 * v + 1] = lds.tree.rng[base + v];
+        dump[8 + 4 * v + 2] = lds.tree.cnt[base + v];
+        dump[8 + 4 * v + 3] = v < leaves ? lds.code[pos0 + v] : 0u;
+    }
+}
+
+void launch_tree_debug(const int32_t* symbols, uint32_t count, int which, int batch, uint32_t* dump,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(tree_debug_kernel, dim3(1), dim3(kWave), 0, stream, symbols, count, which, batch, dump);
 }
 
 void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          const uint32_t* tok_count, uint8_t* out,
                          const uint64_t* out_off, uint64_t* out_bytes,
                          int32_t* err, uint32_t n_blocks,
-                         uint64_t prefix_acc, int prefix_fill, hipStream_t stream) {
+                         uint64_t prefix_acc, int prefix_fill, sqz_block_stats* stats,
+                         hipStream_t stream) {
     if (n_blocks == 0) { return; }
     hipLaunchKernelGGL(huffman_emit_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
                        tokens, tok_off, tok_count, out, out_off, out_bytes, err, n_blocks,
-                       prefix_acc, prefix_fill);
+                       prefix_acc, prefix_fill, stats);
 }
 
 } // namespace sqzk

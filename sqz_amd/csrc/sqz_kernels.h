@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/sqz/sqz.h"      // sqz_block_stats
+
 namespace sqzk {
 
 // stage 1: LZ77 brute-force longest-match scan + greedy parse
@@ -36,7 +38,12 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          const uint32_t* tok_count, uint8_t* out,
                          const uint64_t* out_off, uint64_t* out_bytes,
                          int32_t* err, uint32_t n_blocks,
-                         uint64_t prefix_acc, int prefix_fill, hipStream_t stream);
+                         uint64_t prefix_acc, int prefix_fill, sqz_block_stats* stats,
+                         hipStream_t stream);
+
+// test entry: one tree driven by a symbol sequence, its LDS image dumped (huffman_emit.hip)
+void launch_tree_debug(const int32_t* symbols, uint32_t count, int which, int batch, uint32_t* dump,
+                       hipStream_t stream);
 
 // decode (squeeze.h:502-551): entropy stage -> token words -> LZ77 expansion.
 // tokens: one uint32 slot per OUTPUT byte, addressed by out_off; tok_count[n].

@@ -1,0 +1,981 @@
+// sqz_amd/csrc/sqz_tree.h -- the adaptive Huffman trees of one stream, LDS resident, and their
+// updates (gfx950 only).  Shared by huffman_emit.hip and decode.hip.
+//
+// Reference semantics restated here (file:line relative to /root/reference/attic/map_experiment):
+//   huffman.h:13-34   node / tree           -> TreeLds (three words per node), Tree<> (registers)
+//   huffman.h:41-62   huffman_update_paths  -> depths, codes and leaf intervals kept by FLAT passes
+//                                              (swap_fix / promote_fix / the insert's shift) + the
+//                                              depth mark (mark_subtree); relabel() for deep trees
+//   huffman.h:64-86   huffman_swap_siblings -> order_only (+ swap_fix), the per-level swaps of climb_wave
+//   huffman.h:90-96   huffman_update_freq   -> sum
+//   huffman.h:98-147  move_up / frequency_changed -> changed_all (whole wave), changed (one lane, deep trees)
+//   huffman.h:149-216 huffman_insert        -> insert_wave
+//   huffman.h:218-235 huffman_inc_frequency -> bump_wave (one symbol), bump_batch (up to 64 tokens)
+//
+// One wavefront owns one stream; both trees live in one set of LDS arrays (absolute node ids:
+// the distance tree's ids start at kPosBase, its leaf positions at kPosPos0).
+//
+// THE BATCHED UPDATE.  The reference updates one symbol at a time; 98 % of the updates change no
+// link.  For a batch of symbols the reference would change no link iff, for every node v that
+// some symbol's leaf->root chain passes (parent p, sibling s, uncle u; f = counts before the
+// batch, n(v) = chains through v):
+//     v is lo(p):                 f(v) + n(v) <= f(s)      (never overtakes its sibling)
+//     v is hi(p), p not the root: f(v) + n(v) <= f(u)      (never overtakes its uncle)
+// (induction over the sequential updates: counts only grow, v's count never exceeds f(v)+n(v),
+// s and u never drop below f; a hi child needs no test against its own sibling because every
+// pair is ordered lo <= hi at rest and the reference's exchange can only be triggered from the
+// lo side -- the oracle asserts both at-rest properties after every update, `make -C oracle
+// check-invariants`).  Then the batch leaves f + n on every node and every code is the static
+// tree's.  The tests may be conservative: the token a batch stops at goes through the exact
+// one-at-a-time path, so the output is always the reference's.
+//
+// n(v) WITHOUT WALKING ANY CHAIN.  Every leaf has a position in depth-first order (lo before
+// hi) and every node the interval [st, en) of the leaf positions below it.  With P = prefix sums
+// of the batch's histogram over positions, n(v) = P[en(v)] - P[st(v)] for ALL nodes at once:
+// one independent lookup per node (ten nodes per lane) instead of two dependent walks per
+// token with an LDS atomic on every level.  A node's test partner (sibling or uncle) is cached
+// next to its interval.  If node v fails its test, the first token that may not be applied is
+// the (f(partner) - f(v) + 1)-th one whose position lies in [st(v), en(v)); the earliest such
+// token over all failing nodes ends the batch.  tests/model/range_model.c is this algorithm in
+// plain C, held against the oracle's tree in lockstep (tests/test_range_model.py).
+//
+// KEEPING THE INTERVALS.  A restructure (2 % of the symbols) moves whole subtrees; the exact
+// path does the reference's sequence and repairs intervals, depths, per-leaf codes and cached
+// partners with flat passes over the node arrays -- one lane per node, a few arithmetic
+// selects per node, no subtree walk:
+//     sibling exchange under p:  the two halves of [st(p), en(p)) trade places; one code bit flips
+//     promotion under g:         three neighbouring intervals rotate; one subtree comes up a level
+//                                (a code bit disappears), one goes down (a bit appears)
+//     insert:                    every position behind the split leaf moves one to the right
+//
+// Node words (LDS, 12 B per node):
+//     lnk  up | lo << 10 | hi << 20                    (10-bit absolute ids, 0x3FF = none)
+//     rng  st | en << 9 | partner << 18                (positions < 512; partner 0x3FF = untested)
+//     cnt  count (24 bits) | depth << 24 (6 bits)
+// and for the encoder code[leaf slot]: the leaf's code in STREAM order (first branch = most
+// significant of `depth` bits), valid while the tree is shallower than kCodeDepth.
+#pragma once
+
+#include "sqz_device.h"
+
+namespace sqzk {
+
+constexpr uint32_t kNil = 0x3FFu;
+constexpr int kLitLeaves = 288;               // symbols 0..285 (+2 pad)
+constexpr int kLitNodes  = kLitLeaves + 288;  // root + <=285 splits (+pad)
+constexpr int kPosLeaves = 32;
+constexpr int kPosNodes  = 64;
+constexpr int kPosBase   = kLitNodes;         // first node id of the distance tree
+constexpr int kAllNodes  = kLitNodes + kPosNodes;
+constexpr int kPosPos0   = kLitLeaves;        // first leaf position of the distance tree
+constexpr int kPositions = kLitLeaves + kPosLeaves;     // 320 leaf positions in all
+constexpr int kCodeSlots = kPositions;        // code[]: lit leaf s -> s, pos leaf k -> kPosPos0 + k
+
+constexpr uint32_t kCountMask = (1u << 24) - 1u;
+constexpr int kDepthShift = 24;
+
+// Trees this deep leave the fast machinery for good (batches, interval passes, 32-bit codes):
+// every symbol then takes the reference sequence on the chain held by the wave (depth < kMaxFastDepth)
+// or by one lane.  A chain of depth d needs counts that at least double per level (hi child <=
+// uncle, lo <= hi), i.e. 2^d symbols, so real streams stay far below either limit; the limits can
+// be lowered at build time so that tests reach the deep paths (tools/build_variants.sh).
+#ifndef SQZ_AUX_DEPTH
+#define SQZ_AUX_DEPTH 26
+#endif
+#ifndef SQZ_MAX_FAST_DEPTH
+#define SQZ_MAX_FAST_DEPTH 60
+#endif
+#ifndef SQZ_FREEZE_DEPTH
+#define SQZ_FREEZE_DEPTH 63                   // huffman.h:228 `t->depth < 63`
+#endif
+constexpr int kAuxDepth = SQZ_AUX_DEPTH;
+constexpr int kMaxFastDepth = SQZ_MAX_FAST_DEPTH;
+constexpr int kFreezeDepth = SQZ_FREEZE_DEPTH;
+constexpr int kStack = 128;                   // deepest chain the one-lane path follows (fault beyond)
+// most bits one token hands to a pack: two codes shorter than kAuxDepth bits + 5 + 13 extra bits
+constexpr int kTokenBits = 2 * (kAuxDepth - 1) + 18;
+constexpr int kPackWords = (63 + 58 + kWave * kTokenBits + 63) / 64 + 1;     // carry + pending + 64 tokens
+constexpr int kImageWords = kPackWords > kWave ? kPackWords : kWave;         // (the histogram takes 64 words)
+
+struct TreeLds {
+    uint32_t lnk[kAllNodes];
+    uint32_t rng[kAllNodes];
+    uint32_t cnt[kAllNodes];
+    uint32_t pend[kWave];                     // parent << 16 | child, one per pending level
+    uint16_t lvl[kStack];                     // chain scatter / the one-lane path's stack
+    // one batch: histogram over leaf positions (a byte each), turned into its prefix sums in place
+    // (the first 64 words); the encoder's bit image of a step lives here too, after the update
+    union { uint64_t P64[kImageWords]; uint32_t P32[2 * kImageWords]; uint8_t P8[8 * kImageWords]; };
+};
+
+// huffman.h:29-33 + squeeze.h:397-403, kept only by the kernels' kStats instantiation
+struct TreeStats { uint32_t updates, swaps, moves; };
+
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
+__device__ __forceinline__ uint32_t l_up(uint32_t w) { return w & 0x3FFu; }
+__device__ __forceinline__ uint32_t l_lo(uint32_t w) { return (w >> 10) & 0x3FFu; }
+__device__ __forceinline__ uint32_t l_hi(uint32_t w) { return (w >> 20) & 0x3FFu; }
+__device__ __forceinline__ uint32_t mk_lnk(uint32_t up, uint32_t lo, uint32_t hi) { return up | (lo << 10) | (hi << 20); }
+__device__ __forceinline__ uint32_t r_st(uint32_t w) { return w & 0x1FFu; }
+__device__ __forceinline__ uint32_t r_en(uint32_t w) { return (w >> 9) & 0x1FFu; }
+__device__ __forceinline__ uint32_t r_pa(uint32_t w) { return (w >> 18) & 0x3FFu; }
+__device__ __forceinline__ uint32_t mk_rng(uint32_t st, uint32_t en, uint32_t pa) { return st | (en << 9) | (pa << 18); }
+__device__ __forceinline__ uint32_t c_f(uint32_t w) { return w & kCountMask; }
+__device__ __forceinline__ uint32_t c_d(uint32_t w) { return (w >> kDepthShift) & 0x3Fu; }
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)v, o);
+        v = other > v ? other : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan(v), kWave - 1);
+}
+
+// one lane's share of a root path: its node and that node's parent
+struct Chain {
+    int mine, par;
+    int levels;        // uniform: edges between leaf and root
+    bool holds;        // this lane holds a node of the path
+    bool active;       // ... and the node has a parent
+    bool has_g;        // ... and that parent is not the root
+};
+
+// The slow paths live in real (non-inlined) functions so that the per-step loop of the kernels
+// stays small (I-cache).  State crosses the call as plain values.
+template <class T> __device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
+template <class T> __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
+template <class T> __device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane);
+
+// BASE: first node id; LEAVES / NODES: id space (leaves keep their symbol value + BASE, internal
+// nodes are numbered upwards from the root = BASE + LEAVES; the reference counts down from 2n-2, no
+// emitted bit depends on it); REF_LEAVES: the reference's leaf count n (512 / 32, squeeze.h:204-205),
+// which only fixes how many leaf splits huffman_insert allows (n - 2, huffman.h:180); POS0: first
+// leaf position; LUT_BITS: the decoder's lookup table width.
+template <int BASE, int LEAVES, int NODES, int REF_LEAVES, int POS0, int LUT_BITS, bool CODES>
+struct Tree {
+    TreeLds* lds;
+    uint32_t* code;     // encoder only (CODES): kCodeSlots entries
+    uint16_t* lut;      // decoder only: 2^kLutBits entries, node | bits used << 10
+    // wave-uniform registers
+    int next;           // next free internal id
+    int depth;          // huffman.h:26 high-water mark
+    int complete;       // huffman.h:27
+    int fault;          // stack / depth guard (never set for realistic streams)
+    int aux;            // intervals / partners / codes are kept (tree shallower than kAuxDepth so far)
+    int lut_ok;         // decoder: the lookup table matches the tree
+    TreeStats stats;
+
+    static constexpr int kBase = BASE;
+    static constexpr int kRoot = BASE + LEAVES;
+    static constexpr int kLeaves = LEAVES;
+    static constexpr int kLutBits = LUT_BITS;
+    static constexpr int kIdEnd = BASE + ((LEAVES + 1 + REF_LEAVES - 2) < NODES ? (LEAVES + 1 + REF_LEAVES - 2) : NODES);
+    static constexpr bool kCodes = CODES;
+
+    __device__ __forceinline__ void init_all(int lane) {      // huffman.h:251-269
+        for (int i = BASE + lane; i < BASE + NODES; i += kWave) {
+            lds->lnk[i] = 0x3FFFFFFFu;
+            lds->rng[i] = mk_rng(0, 0, kNil);
+            lds->cnt[i] = 0;
+        }
+        next = kRoot + 1; depth = 0; complete = 0; fault = 0; aux = 1; lut_ok = 0;
+        stats.updates = stats.swaps = stats.moves = 0;
+    }
+
+    __device__ __forceinline__ bool is_leaf(uint32_t v) const { return v < (uint32_t)kRoot; }
+    __device__ __forceinline__ uint32_t up_of(int i) const { return l_up(lds->lnk[i]); }
+    __device__ __forceinline__ uint32_t freq(int i) const { return c_f(lds->cnt[i]); }
+    __device__ __forceinline__ void set_freq(int i, uint32_t f) { lds->cnt[i] = (lds->cnt[i] & ~kCountMask) | (f & kCountMask); }
+    __device__ __forceinline__ void set_depth(int i, uint32_t d) { lds->cnt[i] = (lds->cnt[i] & kCountMask) | (d << kDepthShift); }
+    __device__ __forceinline__ int code_slot(int leaf) const { return leaf - BASE + POS0; }
+
+    // registers <-> one word: next:10 | depth:8 | complete | fault | aux ; bit 31 = the call's own result
+    __device__ __forceinline__ uint32_t pack_regs() const {
+        return (uint32_t)next | ((uint32_t)(depth & 0xFF) << 10) | ((uint32_t)(complete & 1) << 18) |
+               ((uint32_t)(fault & 1) << 19) | ((uint32_t)(aux & 1) << 20);
+    }
+    __device__ __forceinline__ void unpack_regs(uint32_t r) {
+        next = (int)(r & 0x3FFu); depth = (int)((r >> 10) & 0xFFu);
+        complete = (int)((r >> 18) & 1u); fault = (int)((r >> 19) & 1u); aux = (int)((r >> 20) & 1u);
+    }
+    __device__ __forceinline__ void uniform_regs() {
+        next = __builtin_amdgcn_readfirstlane(next);
+        depth = __builtin_amdgcn_readfirstlane(depth);
+        complete = __builtin_amdgcn_readfirstlane(complete);
+        fault = __builtin_amdgcn_readfirstlane(fault);
+        aux = __builtin_amdgcn_readfirstlane(aux);
+    }
+    // the reference's high-water mark moved: a tree this deep gives up the interval machinery
+    __device__ __forceinline__ void raise_mark(int d) {
+        if (d > depth) { depth = d; }
+        if (depth >= kAuxDepth) { aux = 0; }
+    }
+
+    // ---------------- flat passes: one lane per node ----------------------------------------
+    // The depth mark as huffman_update_paths(top) leaves it (huffman.h:44,61): reset when top is
+    // the root, then the deepest node of top's subtree.  Subtree = interval containment + deeper.
+    __device__ __forceinline__ void mark_subtree(int top, int lane) {
+        const uint32_t tr = lds->rng[top];
+        const uint32_t a = r_st(tr), b = r_en(tr), dt = c_d(lds->cnt[top]);
+        uint32_t deepest = dt, visited = 0;
+        for (int v = BASE + lane; v < next; v += kWave) {
+            const uint32_t w = lds->rng[v], d = c_d(lds->cnt[v]);
+            const bool in = r_en(w) > r_st(w) && r_st(w) >= a && r_en(w) <= b && (v == top || d > dt);
+            deepest = (in && d > deepest) ? d : deepest;
+            visited += in ? 1u : 0u;
+        }
+        if (top == kRoot) { depth = 0; }
+        raise_mark((int)wave_max(deepest));
+        stats.updates += wave_sum(visited);                    // huffman.h:42, one per node visited
+    }
+
+    // test partners of the nodes up to `levels` levels below `top` (they are the only ones whose
+    // sibling or uncle a restructure at `top` can have changed): lane j walks down to the j-th
+    // of them (children 0..1, grandchildren 2..5, great-grandchildren 6..13), then up twice
+    __device__ __forceinline__ void fix_partners(int top, int levels, int lane) {
+        const int j = lane + 2;                                // 2..15: the path below `top` in binary, leading 1 dropped
+        const int d = 31 - __clz(j);                           // 1..3 levels down
+        uint32_t v = (uint32_t)top;
+        bool ok = lane < (2 << levels) - 2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k < d) {
+                const uint32_t w = lds->lnk[ok ? v : (uint32_t)kRoot];
+                const uint32_t nx = ((j >> (d - 1 - k)) & 1) ? l_hi(w) : l_lo(w);
+                ok = ok && v >= (uint32_t)kRoot && nx != kNil;
+                v = ok ? nx : v;
+            }
+        }
+        if (ok) {
+            const uint32_t p = l_up(lds->lnk[v]);
+            const uint32_t pw = lds->lnk[p];
+            uint32_t pa = kNil;
+            if (l_hi(pw) != v) { pa = l_hi(pw); }
+            else if (l_up(pw) != kNil) {
+                const uint32_t gw = lds->lnk[l_up(pw)];
+                pa = l_lo(gw) == p ? l_hi(gw) : l_lo(gw);
+            }
+            lds->rng[v] = (lds->rng[v] & 0x3FFFFu) | (pa << 18);
+        }
+        lds_fence();
+    }
+
+    // the two children of p have traded slots (the links already say so): X = the child now in the
+    // lo slot (its interval [m, b) comes first from now on), Y = the child now hi (was [a, m)).
+    // Positions move, one code bit of every leaf below p flips, X and Y trade tests; the depth mark
+    // and the statistics see the walk huffman_swap_siblings makes (huffman.h:76-80).
+    __device__ __forceinline__ void swap_fix(int p, int lane) {
+        stats.swaps += 1;
+        if (aux == 0) {                                        // deep tree: the reference's walk, one lane
+            if (lane == 0) { relabel(p); }
+            uniform_regs();
+            lds_fence();
+            return;
+        }
+        const uint32_t pw = lds->lnk[p];
+        const uint32_t xr = lds->rng[l_lo(pw)], yr = lds->rng[l_hi(pw)];
+        const uint32_t a = r_st(yr), m = r_st(xr), b = r_en(xr);
+        const uint32_t dp = c_d(lds->cnt[p]);
+        uint32_t deepest = dp, visited = 1;
+        for (int v = BASE + lane; v < next; v += kWave) {
+            const uint32_t w = lds->rng[v];
+            const uint32_t s = r_st(w), e = r_en(w);
+            const bool in_x = e > s && s >= m && e <= b, in_y = e > s && s >= a && e <= m;
+            if (in_x | in_y) {
+                const uint32_t d = c_d(lds->cnt[v]);
+                const uint32_t ns = in_x ? s - (m - a) : s + (b - m);
+                lds->rng[v] = (w & ~0x3FFFFu) | ns | ((ns + (e - s)) << 9);
+                if (CODES && is_leaf((uint32_t)v)) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
+                deepest = d > deepest ? d : deepest;
+                visited += 1;
+            }
+        }
+        lds_fence();
+        fix_partners(p, 1, lane);
+        if (p == kRoot) { depth = 0; }
+        raise_mark((int)wave_max(deepest));
+        stats.updates += wave_sum(visited) - (kWave - 1);      // every lane started at 1 for p itself
+    }
+
+    // c (hi child of p) and its uncle u have traded places under g (the links already say so):
+    //   left  (p = lo(g)):  [x][c][u] -> [x][u][c]      c: G01S -> G1S     u: G1S -> G01S
+    //   right (p = hi(g)):  [u][x][c] -> [c][x][u]      c: G11S -> G0S     u: G0S -> G11S
+    // (G = the code of g, S = what follows below the moved node).  c's subtree comes up a level.
+    __device__ __forceinline__ void promote_fix(int g, int p, int c, int u, int left, int lane) {
+        stats.moves += 1;
+        if (aux == 0) { return; }
+        const uint32_t x = l_lo(lds->lnk[p]);
+        const uint32_t cr = lds->rng[c], ur = lds->rng[u], xr = lds->rng[x];
+        const uint32_t ca = r_st(cr), cb = r_en(cr), ua = r_st(ur), ub = r_en(ur), xa = r_st(xr), xb = r_en(xr);
+        const int C = (int)(cb - ca), U = (int)(ub - ua), X = (int)(xb - xa);
+        const uint32_t dg = c_d(lds->cnt[g]);
+        const int dc = left ? U : -(U + X), du = left ? -C : C + X, dx = left ? 0 : C - U;
+        for (int v = BASE + lane; v < next; v += kWave) {
+            const uint32_t w = lds->rng[v];
+            const uint32_t s = r_st(w), e = r_en(w);
+            const bool live = e > s && v != p && v != g;
+            const bool in_c = live && s >= ca && e <= cb, in_u = live && s >= ua && e <= ub;
+            const bool in_x = live && s >= xa && e <= xb;
+            if (in_c | in_u | in_x) {
+                const int shift = in_c ? dc : in_u ? du : dx;
+                const uint32_t ns = (uint32_t)((int)s + shift);
+                lds->rng[v] = (w & ~0x3FFFFu) | ns | ((ns + (e - s)) << 9);
+                if (in_c | in_u) {
+                    const uint32_t cw = lds->cnt[v];
+                    const uint32_t d = c_d(cw);
+                    lds->cnt[v] = in_c ? cw - (1u << kDepthShift) : cw + (1u << kDepthShift);
+                    if (CODES && is_leaf((uint32_t)v)) {
+                        const uint32_t old = code[code_slot(v)];
+                        const uint32_t ls = in_c ? d - dg - 2u : d - dg - 1u;      // bits below the moved node
+                        const uint32_t G = dg != 0 ? old >> (d - dg) : 0u;
+                        const uint32_t S = old & ((1u << ls) - 1u);
+                        const uint32_t head = in_c ? ((G << 1) | (left ? 1u : 0u)) : ((G << 2) | (left ? 1u : 3u));
+                        code[code_slot(v)] = (head << ls) | S;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {                                       // p now holds x and u
+            const uint32_t ps = left ? xa : (uint32_t)((int)xa + dx);
+            lds->rng[p] = (lds->rng[p] & ~0x3FFFFu) | ps | ((ps + (uint32_t)(X + U)) << 9);
+        }
+        lds_fence();
+        fix_partners(g, 3, lane);
+    }
+
+    // ---------------- the reference sequence on one lane (deep trees only) --------------------
+    __device__ __forceinline__ void sum(int i) {               // huffman.h:90-96
+        const uint32_t w = lds->lnk[i];
+        const uint32_t a = l_lo(w) != kNil ? freq((int)l_lo(w)) : 0u;
+        const uint32_t b = l_hi(w) != kNil ? freq((int)l_hi(w)) : 0u;
+        set_freq(i, a + b);
+    }
+
+    // huffman.h:41-62 by a walk: depths below `top`, the mark, the statistics
+    __device__ __forceinline__ void relabel(int top) {
+        if (top == kRoot) { depth = 0; }
+        int sp = 0;
+        lds->lvl[sp++] = (uint16_t)top;
+        while (sp > 0) {
+            const int v = lds->lvl[--sp];
+            const uint32_t w = lds->lnk[v];
+            const int b = (int)c_d(lds->cnt[v]);
+            stats.updates += 1;
+            if (b > depth) { depth = b; }
+            if (b >= 62) { fault = 1; continue; }               // the depth field holds 6 bits; reference asserts bits < 63
+            const uint32_t kids[2] = { l_hi(w), l_lo(w) };
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t ch = kids[j];
+                if (ch == kNil) { continue; }
+                set_depth((int)ch, (uint32_t)(b + 1));
+                if (ch >= (uint32_t)kRoot) {
+                    if (sp < kStack) { lds->lvl[sp++] = (uint16_t)ch; } else { fault = 1; }
+                } else {
+                    stats.updates += 1;
+                    if (b + 1 > depth) { depth = b + 1; }
+                }
+            }
+        }
+        if (depth >= kAuxDepth) { aux = 0; }
+    }
+
+    __device__ __forceinline__ int order_pair(int i) {         // huffman.h:64-86, one lane
+        const uint32_t p = up_of(i);
+        if (p == kNil) { return i; }
+        const uint32_t w = lds->lnk[p];
+        const uint32_t l = l_lo(w), r = l_hi(w);
+        if (l != kNil && r != kNil && freq((int)l) > freq((int)r)) {
+            stats.swaps += 1;
+            lds->lnk[p] = mk_lnk(l_up(w), r, l);
+            relabel((int)p);
+            return i == (int)l ? (int)r : (int)l;
+        }
+        return i;
+    }
+
+    __device__ __forceinline__ int climb(int i, int sp) {      // huffman.h:132-142, one lane
+        for (;;) {
+            const uint32_t p = up_of(i);
+            if (p == kNil) { sum(i); break; }
+            sum((int)p);
+            i = order_pair(i);
+            if (sp < kWave) { lds->pend[sp++] = (p << 16) | (uint32_t)i; }
+            else { fault = 1; }
+            i = (int)p;
+        }
+        return sp;
+    }
+
+    // huffman.h:130-147 with move_up (:98-128) inlined; LIFO order equals the reference's
+    // recursion order because both inner calls are tail calls.  One lane, aux already given up.
+    __device__ __forceinline__ void changed(int start) {
+        int sp = climb(start, 0);
+        while (sp > 0) {
+            const uint32_t e = lds->pend[--sp];
+            const int p = (int)(e >> 16), c = (int)(e & 0xFFFFu);
+            const uint32_t pw = lds->lnk[p];
+            if (l_up(pw) == kNil || l_hi(pw) != (uint32_t)c) { continue; }     // :143
+            const int g = (int)l_up(pw);
+            const uint32_t gw = lds->lnk[g];
+            const bool left = l_lo(gw) == (uint32_t)p;
+            const int uncle = (int)(left ? l_hi(gw) : l_lo(gw));
+            if (!(freq(c) > freq(uncle))) { continue; }                       // :108
+            stats.moves += 1;
+            lds->lnk[c] = (lds->lnk[c] & ~0x3FFu) | (uint32_t)g;
+            lds->lnk[g] = left ? mk_lnk(l_up(gw), l_lo(gw), (uint32_t)c) : mk_lnk(l_up(gw), (uint32_t)c, l_hi(gw));
+            lds->lnk[p] = mk_lnk(l_up(pw), l_lo(pw), (uint32_t)uncle);
+            lds->lnk[uncle] = (lds->lnk[uncle] & ~0x3FFu) | (uint32_t)p;
+            sum(p);
+            sum(g);
+            (void)order_pair(c);
+            (void)order_pair(uncle);
+            (void)order_pair(p);
+            relabel(g);
+            sp = climb(g, sp);                                                // :126
+        }
+    }
+
+    // ---------------- a leaf's root path, one level per lane --------------------------------
+    // lane k receives level k (0 = the leaf).  With intervals: an internal node is an ancestor iff
+    // its interval holds the leaf's position, and its depth says which lane it belongs to -- one
+    // flat pass and a trip through LDS instead of one dependent read per level.
+    __device__ __forceinline__ Chain chain_up(int s, int lane) const {
+        const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[s]);
+        const int levels = (int)c_d(sc);
+        int mine = (int)kNil;
+        if (aux != 0) {
+            const uint32_t q = r_st((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[s]));
+            for (int v = kRoot + lane; v < next; v += kWave) {
+                const uint32_t w = lds->rng[v];
+                const int d = (int)c_d(lds->cnt[v]);
+                // (a node below s on its lo edge holds q as well: only the shallower ones are ancestors)
+                if (r_st(w) <= q && q < r_en(w) && d < levels) { lds->lvl[levels - d] = (uint16_t)v; }
+            }
+            if (lane == 0) { lds->lvl[0] = (uint16_t)s; }
+            lds_fence();
+            mine = lane <= levels ? (int)lds->lvl[lane] : (int)kNil;
+            lds_fence();
+        } else {
+            const int stop = levels < kMaxFastDepth ? levels : kMaxFastDepth;
+            int a = s;
+            mine = lane == 0 ? s : mine;
+            for (int k = 1; k <= stop; k++) {
+                a = __builtin_amdgcn_readfirstlane((int)l_up(lds->lnk[a]));
+                mine = lane == k ? a : mine;
+            }
+        }
+        Chain c;
+        c.mine = mine;
+        c.par = lane_above(mine);            // lane k+1 holds the parent
+        c.levels = levels;
+        c.holds = lane <= levels;
+        c.active = lane < levels;
+        c.has_g = lane + 1 < levels;
+        return c;
+    }
+
+    // ---------------- restructuring, whole wave -------------------------------------------------
+    // sibling order under i's parent (huffman.h:64-86)
+    __device__ __forceinline__ void order_only(int i, int lane) {
+        const uint32_t p = up_of(i);
+        if (p == kNil) { return; }
+        const uint32_t w = lds->lnk[p];
+        const bool swap = l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w));
+        if (swap) {                                            // uniform: every lane read the same words
+            if (lane == 0) { lds->lnk[p] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
+            lds_fence();
+            swap_fix((int)p, lane);
+        }
+    }
+
+    // the climb of huffman_frequency_changed from node i (huffman.h:132-142): lane k owns level
+    // k of i's root path; new sums by prefix sum, sibling order per level, one pending pair per
+    // level (bottom first)
+    __device__ __forceinline__ int climb_wave(int i, int sp, int lane) {
+        const Chain c = chain_up(i, lane);
+        const int levels = c.levels;
+        if (levels >= kMaxFastDepth || sp + levels > kWave) { fault = 1; return 0; }
+        if (levels == 0) {                                            // i is the root
+            if (lane == 0) { sum(i); }
+            lds_fence();
+            return sp;
+        }
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)freq(i));
+        const int x = c.active ? c.mine : kRoot;
+        const int p = c.active ? c.par : kRoot;
+        const uint32_t pw = lds->lnk[p];
+        const bool is_hi = l_hi(pw) == (uint32_t)x;
+        const uint32_t sib = is_hi ? l_lo(pw) : l_hi(pw);
+        const bool has_sib = c.active & (sib != kNil);
+        const uint32_t fs = has_sib ? freq((int)sib) : 0u;
+        const uint32_t incl = wave_scan(c.active ? fs : 0u);
+        const uint32_t fx = f0 + incl - fs;                          // my node's count, refreshed
+        const bool swap = has_sib & (is_hi ? (fs > fx) : (fx > fs));  // lo count > hi count
+        if (c.active) {
+            // the parent sits levels - lane - 1 below the root
+            lds->cnt[p] = ((f0 + incl) & kCountMask) | ((uint32_t)(levels - lane - 1) << kDepthShift);
+            if (swap) { lds->lnk[p] = mk_lnk(l_up(pw), l_hi(pw), l_lo(pw)); }
+            lds->pend[sp + lane] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
+        }
+        lds_fence();
+        uint64_t swaps = __ballot(swap);
+        while (swaps != 0) {                                          // rare: one pass per exchanged pair
+            const int k = __builtin_ctzll(swaps);
+            swaps &= swaps - 1;
+            swap_fix(__builtin_amdgcn_readlane(p, k), lane);
+        }
+        return sp + levels;
+    }
+
+    __device__ __forceinline__ void changed_all(int start, int lane) {
+        int sp = climb_wave(start, 0, lane);
+        while (sp > 0) {
+            // every pending pair at once: the reference pops them from the top and the
+            // ones that fail its tests (:143, :108) change nothing
+            bool hit = false;
+            int p = 0, ch = 0, g = 0, uncle = 0, left = 0;
+            if (lane < sp) {
+                const uint32_t e = lds->pend[lane];
+                p = (int)(e >> 16); ch = (int)(e & 0xFFFFu);
+                const uint32_t pw = lds->lnk[p];
+                if (l_up(pw) != kNil && l_hi(pw) == (uint32_t)ch) {
+                    g = (int)l_up(pw);
+                    const uint32_t gw = lds->lnk[g];
+                    left = l_lo(gw) == (uint32_t)p ? 1 : 0;
+                    uncle = (int)(left ? l_hi(gw) : l_lo(gw));
+                    hit = uncle != (int)kNil && freq(ch) > freq(uncle);
+                }
+            }
+            const uint64_t hits = __ballot(hit);
+            if (hits == 0) { break; }
+            const int j = 63 - __builtin_clzll(hits);
+            sp = j;
+            p = __builtin_amdgcn_readlane(p, j);
+            ch = __builtin_amdgcn_readlane(ch, j);
+            g = __builtin_amdgcn_readlane(g, j);
+            uncle = __builtin_amdgcn_readlane(uncle, j);
+            left = __builtin_amdgcn_readlane(left, j);
+            if (lane == 0) {                                          // move_up, :110-119
+                lds->lnk[ch] = (lds->lnk[ch] & ~0x3FFu) | (uint32_t)g;
+                const uint32_t gw = lds->lnk[g];
+                lds->lnk[g] = left ? mk_lnk(l_up(gw), l_lo(gw), (uint32_t)ch) : mk_lnk(l_up(gw), (uint32_t)ch, l_hi(gw));
+                const uint32_t pw = lds->lnk[p];
+                lds->lnk[p] = mk_lnk(l_up(pw), l_lo(pw), (uint32_t)uncle);
+                lds->lnk[uncle] = (lds->lnk[uncle] & ~0x3FFu) | (uint32_t)p;
+            }
+            lds_fence();
+            if (aux != 0) {
+                promote_fix(g, p, ch, uncle, left, lane);
+            } else {                                                  // depths by a walk (deep tree)
+                stats.moves += 1;
+            }
+            if (lane == 0) { sum(p); sum(g); }                        // :120-121
+            lds_fence();
+            order_only(ch, lane);                                     // :122-124
+            order_only(uncle, lane);
+            order_only(p, lane);
+            if (aux != 0) { mark_subtree(g, lane); }                  // :125 huffman_update_paths(gix)
+            else { if (lane == 0) { relabel(g); } uniform_regs(); lds_fence(); }
+            sp = climb_wave(g, sp, lane);                             // :126
+        }
+    }
+
+    // huffman_inc_frequency for an ATTACHED leaf s whose chain is `c`.
+    // Returns the ballot of "my node is the hi child" (the stream-order code).  Lane k owns level
+    // k of the chain and evaluates exactly the two tests the reference would make at that level
+    // with the incremented counts (swap huffman.h:75, promote :108); no flag -> every count on the
+    // chain grows by one, which the lanes do in one step; any flag -> the reference sequence.
+    __device__ __forceinline__ uint64_t bump_wave(int s, const Chain& c, int lane) {
+        const int i_mine = c.holds ? c.mine : kRoot;
+        const int i_par = c.active ? c.par : kRoot;
+        const uint32_t cw = lds->cnt[i_mine];
+        const uint32_t fc = c_f(cw);
+        const uint32_t pw = lds->lnk[i_par];
+        const bool is_hi = c.active & (l_hi(pw) == (uint32_t)c.mine);
+        const uint64_t code_bits = __ballot(is_hi);
+        if (complete != 0 || depth >= kFreezeDepth) { complete = 1; return code_bits; }   // huffman.h:228-234
+        // my sibling's count; my uncle is my parent's sibling = the lane above
+        const uint32_t sib = is_hi ? l_lo(pw) : l_hi(pw);
+        const bool has_sib = c.active & (sib != kNil);
+        const uint32_t fs = freq(has_sib ? (int)sib : kRoot);
+        const uint32_t fu = (uint32_t)lane_above((int)fs);
+        const bool has_unc = is_hi & c.has_g & (lane_above(has_sib ? 1 : 0) == 1);
+        const uint32_t fc1 = fc + 1;
+        const uint32_t big = is_hi ? fs : fc1;                        // swap iff lo count > hi count
+        const uint32_t small = is_hi ? fc1 : fs;
+        const bool flag = (has_sib & (big > small)) | (has_unc & (fc1 > fu)) |
+                          (c.levels >= kMaxFastDepth);
+        if (__ballot(flag) == 0) {
+            if (c.holds) { lds->cnt[c.mine] = cw + 1; }
+            lds_fence();
+        } else {
+            changed_wave(s, lane);
+        }
+        return code_bits;
+    }
+
+    // ---------------- entry points of the slow paths ----------------------------------------------
+#ifdef SQZ_STATS
+    uint64_t st_cyc[3] = {0, 0, 0};
+    uint32_t st_cnt[3] = {0, 0, 0};
+#define SQZ_ST_BEGIN const uint64_t st_t0 = __builtin_readcyclecounter();
+#define SQZ_ST_END(k) st_cyc[k] += __builtin_readcyclecounter() - st_t0; st_cnt[k]++;
+#else
+#define SQZ_ST_BEGIN
+#define SQZ_ST_END(k)
+#endif
+    __device__ __forceinline__ bool insert_wave(int i, int lane) {
+        SQZ_ST_BEGIN
+        const TreeStats keep = stats;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)slow_insert<Tree>(lds, code, pack_regs(), i, lane));
+        unpack_regs(r);
+        stats = keep;
+        load_stats_delta();
+        lut_ok = 0;
+        SQZ_ST_END(0)
+        return (r >> 31) != 0;
+    }
+
+    __device__ __forceinline__ void changed_wave(int s, int lane) {
+        SQZ_ST_BEGIN
+        const TreeStats keep = stats;
+        unpack_regs((uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)slow_changed<Tree>(lds, code, pack_regs(), s, lane)));
+        stats = keep;
+        load_stats_delta();
+        lut_ok = 0;
+        SQZ_ST_END(1)
+    }
+
+    // the slow calls leave what they counted in pend[61..63] (nothing is pending between calls)
+    __device__ __forceinline__ void store_stats_delta(int lane) {
+        if (lane == 0) { lds->pend[61] = stats.updates; lds->pend[62] = stats.swaps; lds->pend[63] = stats.moves; }
+        lds_fence();
+    }
+    __device__ __forceinline__ void load_stats_delta() {
+        stats.updates += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[61]);
+        stats.swaps += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[62]);
+        stats.moves += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[63]);
+    }
+
+    __device__ __forceinline__ void build_lut(int lane) {
+        SQZ_ST_BEGIN
+        slow_build_lut<Tree>(lds->lnk, lut, lane);
+        lut_ok = 1;
+        SQZ_ST_END(2)
+    }
+
+    // ---------------- huffman_insert (huffman.h:149-216), whole wave -------------------------------
+    // lane 0 hangs the leaf into the links; positions, codes and partners follow by flat passes; then
+    // the climb and the promotions like any other update, and the closing walk of :213.
+    __device__ __forceinline__ bool insert_all(int i, int lane) {
+        uint32_t hand = 0;       // start | at << 10 | ok << 20 | split << 21 ; q in the high bits
+        if (lane == 0) {
+            uint32_t ok = 1, split = 0, q = 0;
+            int at = kRoot, leaf = i;
+            lds->cnt[leaf] = 1u;                                       // freq 1, depth set below
+            uint32_t aw = 0;
+            while (at >= kRoot) {                                      // :156-170
+                aw = lds->lnk[at];
+                if (l_hi(aw) == kNil || l_lo(aw) == kNil) { break; }
+                at = (int)l_lo(aw);
+            }
+            if (at >= kRoot) {                                         // :171-173: hangs under the root (the first two leaves)
+                const bool to_hi = l_hi(aw) == kNil;
+                lds->lnk[at] = to_hi ? mk_lnk(l_up(aw), l_lo(aw), (uint32_t)leaf) : mk_lnk(l_up(aw), (uint32_t)leaf, l_hi(aw));
+                lds->lnk[leaf] = mk_lnk((uint32_t)at, kNil, kNil);
+                set_freq(at, freq(at) + 1u);
+                // the tree is tiny (at IS the root: a split always makes two children): rebuild its aux by hand
+                const uint32_t d = c_d(lds->cnt[at]) + 1u;
+                set_depth(leaf, d);
+                const uint32_t w2 = lds->lnk[at];
+                const uint32_t lo = l_lo(w2), hi = l_hi(w2);
+                uint32_t pos = (uint32_t)POS0;
+                if (lo != kNil) {
+                    lds->rng[lo] = mk_rng(pos, pos + 1, hi);           // a lo child is tested against its sibling
+                    if (CODES) { code[code_slot((int)lo)] = 0u; }
+                    pos++;
+                }
+                if (hi != kNil) {
+                    lds->rng[hi] = mk_rng(pos, pos + 1, kNil);         // a hi child of the root has no test
+                    if (CODES) { code[code_slot((int)hi)] = 1u; }
+                    pos++;
+                }
+                lds->rng[at] = mk_rng((uint32_t)POS0, pos, kNil);
+            } else if (next >= kIdEnd) {                               // :180-182
+                ok = 0;
+                complete = 1;
+            } else {                                                   // :184-209: split leaf `at`
+                split = 1;
+                const int fresh = next++;
+                const uint32_t above = l_up(lds->lnk[at]);
+                const uint32_t acw = lds->cnt[at];
+                q = r_st(lds->rng[at]);
+                lds->lnk[fresh] = mk_lnk(above, (uint32_t)at, (uint32_t)leaf);
+                lds->cnt[fresh] = acw;                                 // at's count and depth
+                const uint32_t bw = lds->lnk[above];
+                lds->lnk[above] = l_lo(bw) == (uint32_t)at ? mk_lnk(l_up(bw), (uint32_t)fresh, l_hi(bw))
+                                                           : mk_lnk(l_up(bw), l_lo(bw), (uint32_t)fresh);
+                lds->lnk[at] = mk_lnk((uint32_t)fresh, kNil, kNil);
+                lds->lnk[leaf] = mk_lnk((uint32_t)fresh, kNil, kNil);
+                lds->cnt[at] = acw + (1u << kDepthShift);
+                lds->cnt[leaf] = 1u | ((c_d(acw) + 1u) << kDepthShift);
+                sum(fresh);
+                at = fresh;
+            }
+            hand = (uint32_t)leaf | ((uint32_t)at << 10) | (ok << 20) | (split << 21) | (q << 22);
+        }
+        uniform_regs();
+        hand = (uint32_t)__builtin_amdgcn_readfirstlane((int)hand);
+        lds_fence();
+        int start = (int)(hand & 0x3FFu);
+        const int at = (int)((hand >> 10) & 0x3FFu);
+        const bool ok = ((hand >> 20) & 1u) != 0, split = ((hand >> 21) & 1u) != 0;
+        const uint32_t q = hand >> 22;
+        if (split && aux != 0) {
+            // every position behind q moves one to the right, then the three nodes of the split
+            const int fresh = at;
+            for (int v = BASE + lane; v < next; v += kWave) {
+                const uint32_t w = lds->rng[v];
+                const uint32_t s = r_st(w), e = r_en(w);
+                if (e > s && v != fresh && v != i) {
+                    const uint32_t ns = s > q ? s + 1 : s, ne = e > q ? e + 1 : e;
+                    if (ne != e) { lds->rng[v] = (w & ~0x3FFFFu) | ns | (ne << 9); }
+                }
+            }
+            lds_fence();
+            if (lane == 0) {
+                const uint32_t leaf_at = l_lo(lds->lnk[fresh]);
+                lds->rng[fresh] = mk_rng(q, q + 2, kNil);
+                lds->rng[leaf_at] = mk_rng(q, q + 1, kNil);            // (its end was moved by the pass: set it again)
+                lds->rng[i] = mk_rng(q + 1, q + 2, kNil);
+                if (CODES) {
+                    const uint32_t oc = code[code_slot((int)leaf_at)];
+                    code[code_slot((int)leaf_at)] = oc << 1;
+                    code[code_slot(i)] = (oc << 1) | 1u;
+                }
+            }
+            lds_fence();
+            fix_partners((int)l_up(lds->lnk[fresh]), 2, lane);         // fresh, its sibling, and their children
+        }
+        if (!split && ok) {                                            // :173 order under the root
+            const uint32_t w = lds->lnk[at];
+            if (l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w))) {
+                if (lane == 0) { lds->lnk[at] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
+                lds_fence();
+                start = start == (int)l_lo(w) ? (int)l_hi(w) : (int)l_lo(w);
+                swap_fix(at, lane);
+            }
+        }
+        if (aux == 0 || depth + 4 >= kMaxFastDepth) {                  // deep tree: the reference sequence on one lane
+            aux = 0;
+            if (lane == 0) { changed(start); relabel(at); }
+            uniform_regs();
+            lds_fence();
+        } else {
+            changed_all(start, lane);                                  // :212
+            if (aux != 0) { mark_subtree(at, lane); }                  // :213
+            else { if (lane == 0) { relabel(at); } uniform_regs(); lds_fence(); }
+        }
+        return ok;
+    }
+};
+
+template <class T>
+__device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane) {
+    T t;
+    t.lds = lds; t.code = code; t.lut = nullptr; t.lut_ok = 0;
+    t.stats.updates = t.stats.swaps = t.stats.moves = 0;
+    t.unpack_regs(regs);
+    const bool ok = t.insert_all(sym, lane);
+    t.store_stats_delta(lane);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(t.pack_regs() | (ok ? 0x80000000u : 0u)));
+}
+
+template <class T>
+__device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane) {
+    T t;
+    t.lds = lds; t.code = code; t.lut = nullptr; t.lut_ok = 0;
+    t.stats.updates = t.stats.swaps = t.stats.moves = 0;
+    t.unpack_regs(regs);
+    if (lane == 0) { t.lds->cnt[sym] += 1u; }
+    lds_fence();
+    if (t.aux == 0 || t.depth + 4 >= kMaxFastDepth) {   // deep tree: one lane, explicit stacks
+        t.aux = 0;
+        if (lane == 0) { t.changed(sym); }
+        t.uniform_regs();
+        lds_fence();
+    } else {
+        t.changed_all(sym, lane);
+    }
+    t.store_stats_delta(lane);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs());
+}
+
+// decoder: table over the next kLutBits stream bits -> (node reached, bits used).
+// Entry = node | used << 10; a missing child gives node = kNil.
+// One step of the table build: the entry for a prefix one bit longer than `parent`'s.
+// A finished entry (leaf, or a missing child) is inherited; an internal node hands
+// down the child the new bit selects, with one more bit used.
+template <class T>
+__device__ __forceinline__ uint32_t lut_descend(const uint32_t* lnk, uint32_t parent, int bit, int level) {
+    const uint32_t node = parent & 0x3FFu;
+    const bool inside = node != kNil && node >= (uint32_t)T::kRoot;
+    const uint32_t w = lnk[inside ? (int)node : (int)T::kRoot];
+    const uint32_t child = bit ? l_hi(w) : l_lo(w);
+    return inside ? (child | ((uint32_t)level << 10)) : parent;
+}
+
+template <class T>
+__device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane) {
+    // level by level from the root: the table for (L+1)-bit prefixes follows from the one
+    // for L-bit prefixes with one link read per entry.  Lane j holds entry j while a level fits the wave.
+    static_assert(T::kLutBits == 6 || T::kLutBits == 8, "table widths the decoder uses");
+    const int half = (lane >> 1) * 4;                         // byte address of lane j>>1
+    const int bit = lane & 1;
+    uint32_t e = (uint32_t)T::kRoot;                          // the 0-bit prefix: root, no bits used
+#pragma unroll
+    for (int level = 1; level <= 6; level++) {
+        const uint32_t parent = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)e);
+        e = lut_descend<T>(lnk, parent, bit, level);
+    }
+    if (T::kLutBits == 6) {
+        lut[lane] = (uint16_t)e;
+        return;
+    }
+    // 128 entries: j and j + 64 descend from entries j>>1 and 32 + (j>>1) of level 6
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)e);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)e);
+    const uint32_t r0 = lut_descend<T>(lnk, p0, bit, 7);
+    const uint32_t r1 = lut_descend<T>(lnk, p1, bit, 7);
+    // 256 entries: j + 64k descends from entry 32k + (j>>1) of level 7 (r0: 0..63, r1: 64..127)
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)r0);
+    const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)r0);
+    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(half, (int)r1);
+    const uint32_t q3 = (uint32_t)__builtin_amdgcn_ds_bpermute(half + 128, (int)r1);
+    lut[lane]       = (uint16_t)lut_descend<T>(lnk, q0, bit, 8);
+    lut[lane + 64]  = (uint16_t)lut_descend<T>(lnk, q1, bit, 8);
+    lut[lane + 128] = (uint16_t)lut_descend<T>(lnk, q2, bit, 8);
+    lut[lane + 192] = (uint16_t)lut_descend<T>(lnk, q3, bit, 8);
+}
+
+template <bool CODES> using LitTreeT = Tree<0, kLitLeaves, kLitNodes, 512, 0, 8, CODES>;
+template <bool CODES> using PosTreeT = Tree<kPosBase, kPosLeaves, kPosNodes, 32, kPosPos0, 6, CODES>;
+
+// ---------------------------------------------------------------------------------------------
+// Up to 64 tokens per step: lane = token (its lit-tree leaf `a`, then, for a back reference, its
+// distance-tree leaf `b`; absolute node ids, -1 = none).  See the head of this file.
+//
+// Returns how many leading tokens were applied (0..m).  code_a/depth_a/code_b/depth_b are the
+// static tree's and valid for all m lanes (kWantCode: the encoder emits them, the decoder has no
+// use for them).  Only callable while both trees keep their intervals (aux) and take updates.
+template <bool kWantCode, class LIT, class POS>
+__device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, const LIT& lit, const POS& pos,
+                                          int lane, int m, int a, int b,
+                                          uint32_t& code_a, int& depth_a, uint32_t& code_b, int& depth_b) {
+    const bool take = lane < m;
+    const bool has_a = take && a >= 0, has_b = take && b >= 0;
+    const int ia = has_a ? a : LIT::kRoot, ib = has_b ? b : POS::kRoot;
+    const uint32_t ra = lds->rng[ia], rb = lds->rng[ib];
+    const uint32_t qa = r_st(ra), qb = r_st(rb);
+    depth_a = (int)c_d(lds->cnt[ia]);
+    depth_b = (int)c_d(lds->cnt[ib]);
+    if (kWantCode) {
+        code_a = code[has_a ? ia - LIT::kBase + 0 : 0];
+        code_b = code[has_b ? ib - POS::kBase + kPosPos0 : 0];
+    }
+    // ---- histogram over positions (a byte each), then its prefix sums in place ----------------
+    auto histogram = [&](int upto) {
+        lds->P64[lane] = 0ull;
+        lds_fence();
+        if (lane < upto && has_a) { atomicAdd(&lds->P32[qa >> 2], 1u << (8u * (qa & 3u))); }
+        if (lane < upto && has_b) { atomicAdd(&lds->P32[qb >> 2], 1u << (8u * (qb & 3u))); }
+        lds_fence();
+        // lane l owns positions 8l .. 8l+7: byte-wise inclusive sums by one multiply (no byte
+        // overflows: a batch holds at most 128 symbols), then the lanes' totals
+        const uint64_t h = lds->P64[lane];
+        const uint64_t incl = h * 0x0101010101010101ull;
+        const uint32_t total = (uint32_t)(incl >> 56);
+        const uint32_t base = wave_scan(total) - total;
+        lds->P64[lane] = (incl << 8) + (uint64_t)base * 0x0101010101010101ull;     // exclusive: P[i] = symbols at positions < i
+        lds_fence();
+    };
+    histogram(m);
+    // ---- every touched node's test ---------------------------------------------------------------
+    int ok = m;
+    auto test = [&](int v, bool on, uint32_t& n_out) {
+        const uint32_t w = lds->rng[v];
+        const uint32_t n = on ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
+        n_out = n;
+        const uint32_t pa = r_pa(w);
+        const bool tested = n != 0 && pa != kNil;
+        const uint32_t f = c_f(lds->cnt[v]);
+        const uint32_t fb = c_f(lds->cnt[tested ? pa : (uint32_t)v]);
+        const bool viol = tested && f + n > fb;
+        uint64_t vm = __ballot(viol);
+        while (vm != 0) {                                   // rare: find the token that may not pass
+            const int k = __builtin_ctzll(vm);
+            vm &= vm - 1;
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)w, k);
+            const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)f, k);
+            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)fb, k);
+            const uint32_t allowed = bk > fk ? bk - fk : 0u;     // tokens through the node that may pass
+            const uint32_t s = r_st(wk), e = r_en(wk);
+            const bool through = (has_a && qa >= s && qa < e) || (has_b && qb >= s && qb < e);
+            const uint64_t tm = __ballot(through);
+            const uint64_t first_bad = __ballot(through && lanes_under(tm) == allowed);
+            if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
+        }
+    };
+    // the tokens' own leaves (duplicates test the same node twice: harmless), then the internal nodes
+    uint32_t na, nb;
+    test(ia, has_a, na);
+    test(ib, has_b, nb);
+    constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
+    uint32_t nl[kLitRows], np;
+#pragma unroll
+    for (int r = 0; r < kLitRows; r++) {
+        const int v = LIT::kRoot + r * kWave + lane;
+        if (LIT::kRoot + r * kWave < lit.next) { test(v < lit.next ? v : LIT::kRoot, v < lit.next && v != LIT::kRoot, nl[r]); }
+        else { nl[r] = 0; }
+    }
+    {
+        const int v = POS::kRoot + lane;
+        test(v < pos.next ? v : POS::kRoot, v < pos.next && v != POS::kRoot, np);
+    }
+    // ---- apply the prefix ----------------------------------------------------------------------------
+    if (ok < m) {                                               // cut short: count again for the prefix only
+        histogram(ok);
+#pragma unroll
+        for (int r = 0; r < kLitRows; r++) {
+            const int v = LIT::kRoot + r * kWave + lane;
+            const uint32_t w = lds->rng[v < lit.next ? v : LIT::kRoot];
+            nl[r] = (v < lit.next && v != LIT::kRoot) ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
+        }
+        const int v = POS::kRoot + lane;
+        const uint32_t w = lds->rng[v < pos.next ? v : POS::kRoot];
+        np = (v < pos.next && v != POS::kRoot) ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
+    }
+    // leaves: one add per token (lanes holding the same symbol meet at its leaf); internal nodes:
+    // one add per node, by the lane that tested it
+    if (lane < ok && has_a) { atomicAdd(&lds->cnt[ia], 1u); }
+    if (lane < ok && has_b) { atomicAdd(&lds->cnt[ib], 1u); }
+#pragma unroll
+    for (int r = 0; r < kLitRows; r++) {
+        const int v = LIT::kRoot + r * kWave + lane;
+        if (nl[r] != 0) { lds->cnt[v] += nl[r]; }
+    }
+    if (np != 0) { lds->cnt[POS::kRoot + lane] += np; }
+    lds_fence();
+    return ok;
+}
+
+} // namespace sqzk
