@@ -792,7 +792,7 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
 
 int sqz_hip_debug_tree(const int32_t* d_symbols, uint32_t count, int which, int batch,
                        uint32_t* d_dump, void* stream) {
-    if (d_symbols == NULL || d_dump == NULL || (which != 0 && which != 1)) { return EINVAL; }
+    if (d_symbols == NULL || d_dump == NULL || ((which & 0xFF) != 0 && (which & 0xFF) != 1)) { return EINVAL; }
     const int e = device_ready();
     if (e != 0) { return e; }
     sqzk::launch_tree_debug(d_symbols, count, which, batch, d_dump, (hipStream_t)stream);

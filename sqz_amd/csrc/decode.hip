@@ -238,7 +238,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                     if (k * 32 + 32 <= r.readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
                     lds.stage[h * kWave + lane] = v;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_fence();
             }
             // this lane's 64 stream bits from its offset
             const uint64_t o = base + (uint32_t)lane;
@@ -332,7 +332,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         }
         m = m < kWave ? m : kWave;
         ST_SEC(1)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_fence();
         // ---- lane j = token j: positions, validity, symbols ---------------------------------
         uint32_t word_v = 0, used_v = 0;
         if (lane < m) { const uint32_t sl = slot[lane]; word_v = sl & 0x81FFFFFFu; used_v = ((sl >> 25) & 63u) + 1u; }

@@ -403,15 +403,21 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 // then per node id v of the tree (NODES of them): lnk, rng, cnt, code (leaves; 0 otherwise).
 template <class T>
 __device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, EmitLds& lds, const int32_t* symbols,
-                                            uint32_t count, int batch, int lane, bool is_pos) {
+                                            uint32_t count, int batch, int lane, bool is_pos, bool stop_early,
+                                            uint32_t max_steps, uint32_t& consumed) {
     uint32_t k = 0;
-    while (k < count) {
+    for (uint32_t step = 0; k < count && t.fault == 0 && (max_steps == 0 || step < max_steps); step++) {
+        if (stop_early && t.aux == 0) { break; }               // (bisecting: do not crawl on after the intervals are lost)
+#ifdef SQZ_DEBUG_TREE
+        g_dbg_on = (k + 8 >= count) ? 1 : 0;
+        if (g_dbg_on && lane == 0) { printf("drive k=%u\n", k); }
+#endif
         int sym = -1;
         if (k + (uint32_t)lane < count) { sym = symbols[k + lane]; }
         const bool valid = sym >= 0 && sym < T::kLeaves && lane < batch;
         const int leaf = valid ? T::kBase + sym : T::kRoot;
         const uint64_t seen = __ballot(valid && c_d(lds.tree.cnt[leaf]) != 0);
-        int m = __builtin_ctzll(~seen);                       // leading attached symbols (0..64)
+        int m = (~seen == 0ull) ? kWave : __builtin_ctzll(~seen);   // leading attached symbols (0..64)
         const bool frozen = t.complete != 0 || t.depth >= kFreezeDepth || t.aux == 0;
         uint32_t ca, cb; int wa, wb;
         if (m > 0 && !frozen) {
@@ -429,6 +435,7 @@ __device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, Em
             k++;
         }
     }
+    consumed = k;
 }
 
 __global__ __launch_bounds__(kWave)
@@ -443,10 +450,15 @@ void tree_debug_kernel(const int32_t* __restrict__ symbols, uint32_t count, int 
     pos.init_all(lane);
     for (int k = lane; k < kCodeSlots; k += kWave) { lds.code[k] = 0; }
     __syncthreads();
+    const bool stop_early = (batch & 0x100) != 0;
+    batch &= 0xFF;
     if (batch < 1) { batch = 1; }
     if (batch > kWave) { batch = kWave; }
-    if (which == 0) { debug_drive(lit, lit, pos, lds, symbols, count, batch, lane, false); }
-    else { debug_drive(pos, lit, pos, lds, symbols, count, batch, lane, true); }
+    const uint32_t max_steps = (uint32_t)which >> 8;       // development: stop after this many steps (0 = run to the end)
+    which &= 1;
+    uint32_t consumed = 0;
+    if (which == 0) { debug_drive(lit, lit, pos, lds, symbols, count, batch, lane, false, stop_early, max_steps, consumed); }
+    else { debug_drive(pos, lit, pos, lds, symbols, count, batch, lane, true, stop_early, max_steps, consumed); }
     lds_fence();
     const int base = which == 0 ? 0 : kPosBase, nodes = which == 0 ? kLitNodes : kPosNodes;
     const int leaves = which == 0 ? kLitLeaves : kPosLeaves, pos0 = which == 0 ? 0 : kPosPos0;
@@ -456,7 +468,7 @@ void tree_debug_kernel(const int32_t* __restrict__ symbols, uint32_t count, int 
         dump[1] = (uint32_t)(which == 0 ? lit.depth : pos.depth);
         dump[2] = (uint32_t)(which == 0 ? lit.complete : pos.complete);
         dump[3] = (uint32_t)(which == 0 ? lit.aux : pos.aux);
-        dump[4] = (uint32_t)(which == 0 ? lit.fault : pos.fault);
+        dump[4] = (uint32_t)(which == 0 ? lit.fault : pos.fault) | (max_steps != 0 ? consumed << 8 : 0u);
         dump[5] = st.updates; dump[6] = st.swaps; dump[7] = st.moves;
     }
     for (int v = lane; v < nodes; v += kWave) {

@@ -97,6 +97,10 @@ constexpr int kTokenBits = 2 * (kAuxDepth - 1) + 18;
 constexpr int kPackWords = (63 + 58 + kWave * kTokenBits + 63) / 64 + 1;     // carry + pending + 64 tokens
 constexpr int kImageWords = kPackWords > kWave ? kPackWords : kWave;         // (the histogram takes 64 words)
 
+#ifdef SQZ_DEBUG_TREE
+__device__ int g_dbg_on = 0;      // development tracing: only while this is set
+#endif
+
 struct TreeLds {
     uint32_t lnk[kAllNodes];
     uint32_t rng[kAllNodes];
@@ -111,7 +115,16 @@ struct TreeLds {
 // huffman.h:29-33 + squeeze.h:397-403, kept only by the kernels' kStats instantiation
 struct TreeStats { uint32_t updates, swaps, moves; };
 
-__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Lanes of the wave talk to each other through LDS: a store or atomic by one lane, then a load by
+// another.  The hardware executes one wave's LDS instructions in issue order, so all that is
+// needed is that the COMPILER keeps them in program order -- a release fence alone does not (it
+// lets a later load move above an earlier atomic on a "different" type; seen on gfx950: the
+// histogram's ds_add landed after the ds_read of the prefix sum).  Full fence, wavefront scope:
+// no instruction is emitted for it.
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("" ::: "memory");
+}
 
 __device__ __forceinline__ uint32_t l_up(uint32_t w) { return w & 0x3FFu; }
 __device__ __forceinline__ uint32_t l_lo(uint32_t w) { return (w >> 10) & 0x3FFu; }
@@ -221,8 +234,8 @@ struct Tree {
     // The depth mark as huffman_update_paths(top) leaves it (huffman.h:44,61): reset when top is
     // the root, then the deepest node of top's subtree.  Subtree = interval containment + deeper.
     __device__ __forceinline__ void mark_subtree(int top, int lane) {
-        const uint32_t tr = lds->rng[top];
-        const uint32_t a = r_st(tr), b = r_en(tr), dt = c_d(lds->cnt[top]);
+        const uint32_t tr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[top]);
+        const uint32_t a = r_st(tr), b = r_en(tr), dt = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[top]));
         uint32_t deepest = dt, visited = 0;
         for (int v = BASE + lane; v < next; v += kWave) {
             const uint32_t w = lds->rng[v], d = c_d(lds->cnt[v]);
@@ -278,10 +291,15 @@ struct Tree {
             lds_fence();
             return;
         }
+#ifdef SQZ_DEBUG_TREE
+        if (g_dbg_on && lane == 0) { printf("swap_fix p=%d lnk=%x\n", p, lds->lnk[p]); }
+#endif
+        // (read by one lane and broadcast: the pass below rewrites these very words)
         const uint32_t pw = lds->lnk[p];
-        const uint32_t xr = lds->rng[l_lo(pw)], yr = lds->rng[l_hi(pw)];
+        const uint32_t xr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[l_lo(pw)]);
+        const uint32_t yr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[l_hi(pw)]);
         const uint32_t a = r_st(yr), m = r_st(xr), b = r_en(xr);
-        const uint32_t dp = c_d(lds->cnt[p]);
+        const uint32_t dp = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[p]));
         uint32_t deepest = dp, visited = 1;
         for (int v = BASE + lane; v < next; v += kWave) {
             const uint32_t w = lds->rng[v];
@@ -310,11 +328,17 @@ struct Tree {
     __device__ __forceinline__ void promote_fix(int g, int p, int c, int u, int left, int lane) {
         stats.moves += 1;
         if (aux == 0) { return; }
+#ifdef SQZ_DEBUG_TREE
+        if (g_dbg_on && lane == 0) { printf("promote_fix g=%d p=%d c=%d u=%d left=%d rng c=%x u=%x\n", g, p, c, u, left, lds->rng[c], lds->rng[u]); }
+#endif
+        // (read by one lane and broadcast: the pass below rewrites these very words)
         const uint32_t x = l_lo(lds->lnk[p]);
-        const uint32_t cr = lds->rng[c], ur = lds->rng[u], xr = lds->rng[x];
+        const uint32_t cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[c]);
+        const uint32_t ur = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[u]);
+        const uint32_t xr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[x]);
         const uint32_t ca = r_st(cr), cb = r_en(cr), ua = r_st(ur), ub = r_en(ur), xa = r_st(xr), xb = r_en(xr);
         const int C = (int)(cb - ca), U = (int)(ub - ua), X = (int)(xb - xa);
-        const uint32_t dg = c_d(lds->cnt[g]);
+        const uint32_t dg = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[g]));
         const int dc = left ? U : -(U + X), du = left ? -C : C + X, dx = left ? 0 : C - U;
         for (int v = BASE + lane; v < next; v += kWave) {
             const uint32_t w = lds->rng[v];
@@ -362,7 +386,8 @@ struct Tree {
         if (top == kRoot) { depth = 0; }
         int sp = 0;
         lds->lvl[sp++] = (uint16_t)top;
-        while (sp > 0) {
+        for (int guard = 0; sp > 0; guard++) {
+            if (guard >= NODES) { fault = 1; break; }            // more visits than nodes: the links are corrupt
             const int v = lds->lvl[--sp];
             const uint32_t w = lds->lnk[v];
             const int b = (int)c_d(lds->cnt[v]);
@@ -401,7 +426,8 @@ struct Tree {
     }
 
     __device__ __forceinline__ int climb(int i, int sp) {      // huffman.h:132-142, one lane
-        for (;;) {
+        for (int guard = 0; ; guard++) {
+            if (guard >= kStack) { fault = 1; break; }
             const uint32_t p = up_of(i);
             if (p == kNil) { sum(i); break; }
             sum((int)p);
@@ -417,7 +443,8 @@ struct Tree {
     // recursion order because both inner calls are tail calls.  One lane, aux already given up.
     __device__ __forceinline__ void changed(int start) {
         int sp = climb(start, 0);
-        while (sp > 0) {
+        for (int guard = 0; sp > 0; guard++) {
+            if (guard >= 4 * kStack) { fault = 1; break; }
             const uint32_t e = lds->pend[--sp];
             const int p = (int)(e >> 16), c = (int)(e & 0xFFFFu);
             const uint32_t pw = lds->lnk[p];
@@ -471,6 +498,9 @@ struct Tree {
                 mine = lane == k ? a : mine;
             }
         }
+#ifdef SQZ_DEBUG_TREE
+        if (g_dbg_on && lane < 6) { printf("chain_up s=%d lane=%d levels=%d mine=%d aux=%d next=%d\n", s, lane, levels, mine, aux, next); }
+#endif
         Chain c;
         c.mine = mine;
         c.par = lane_above(mine);            // lane k+1 holds the parent
@@ -487,8 +517,9 @@ struct Tree {
         const uint32_t p = up_of(i);
         if (p == kNil) { return; }
         const uint32_t w = lds->lnk[p];
-        const bool swap = l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w));
-        if (swap) {                                            // uniform: every lane read the same words
+        const bool swap = __builtin_amdgcn_readfirstlane(
+            (l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w))) ? 1 : 0) != 0;
+        if (swap) {
             if (lane == 0) { lds->lnk[p] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
             lds_fence();
             swap_fix((int)p, lane);
@@ -518,6 +549,9 @@ struct Tree {
         const uint32_t incl = wave_scan(c.active ? fs : 0u);
         const uint32_t fx = f0 + incl - fs;                          // my node's count, refreshed
         const bool swap = has_sib & (is_hi ? (fs > fx) : (fx > fs));  // lo count > hi count
+#ifdef SQZ_DEBUG_TREE
+        if (g_dbg_on && lane < 6) { printf("climb i=%d lane=%d x=%d p=%d sib=%u fs=%u fx=%u swap=%d active=%d\n", i, lane, x, p, sib, fs, fx, (int)swap, (int)c.active); }
+#endif
         if (c.active) {
             // the parent sits levels - lane - 1 below the root
             lds->cnt[p] = ((f0 + incl) & kCountMask) | ((uint32_t)(levels - lane - 1) << kDepthShift);
@@ -536,7 +570,10 @@ struct Tree {
 
     __device__ __forceinline__ void changed_all(int start, int lane) {
         int sp = climb_wave(start, 0, lane);
-        while (sp > 0) {
+        // (a promotion moves a node up, so a symbol's update makes fewer of them than the tree is
+        // deep; the bound only keeps a wave from spinning on a corrupted tree: it faults instead)
+        for (int guard = 0; sp > 0; guard++) {
+            if (guard >= 4 * kWave) { fault = 1; break; }
             // every pending pair at once: the reference pops them from the top and the
             // ones that fail its tests (:143, :108) change nothing
             bool hit = false;
@@ -554,6 +591,10 @@ struct Tree {
                 }
             }
             const uint64_t hits = __ballot(hit);
+#ifdef SQZ_DEBUG_TREE
+            if (g_dbg_on && lane == 0) { printf("changed_all sp=%d hits=%llx guard=%d\n", sp, (unsigned long long)hits, guard); }
+            if (g_dbg_on && lane < sp && lane < 8) { printf("  pend lane=%d p=%d ch=%d g=%d uncle=%d hit=%d\n", lane, p, ch, g, uncle, (int)hit); }
+#endif
             if (hits == 0) { break; }
             const int j = 63 - __builtin_clzll(hits);
             sp = j;
@@ -669,6 +710,7 @@ struct Tree {
     __device__ __forceinline__ void build_lut(int lane) {
         SQZ_ST_BEGIN
         slow_build_lut<Tree>(lds->lnk, lut, lane);
+        lds_fence();                                           // entries written by other lanes are read next
         lut_ok = 1;
         SQZ_ST_END(2)
     }
@@ -683,9 +725,10 @@ struct Tree {
             int at = kRoot, leaf = i;
             lds->cnt[leaf] = 1u;                                       // freq 1, depth set below
             uint32_t aw = 0;
-            while (at >= kRoot) {                                      // :156-170
+            for (int guard = 0; at >= kRoot; guard++) {                // :156-170
                 aw = lds->lnk[at];
                 if (l_hi(aw) == kNil || l_lo(aw) == kNil) { break; }
+                if (guard >= kStack) { fault = 1; break; }             // a corrupted tree must not spin the wave
                 at = (int)l_lo(aw);
             }
             if (at >= kRoot) {                                         // :171-173: hangs under the root (the first two leaves)
@@ -768,7 +811,8 @@ struct Tree {
         }
         if (!split && ok) {                                            // :173 order under the root
             const uint32_t w = lds->lnk[at];
-            if (l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w))) {
+            if (__builtin_amdgcn_readfirstlane(
+                    (l_lo(w) != kNil && l_hi(w) != kNil && freq((int)l_lo(w)) > freq((int)l_hi(w))) ? 1 : 0) != 0) {
                 if (lane == 0) { lds->lnk[at] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
                 lds_fence();
                 start = start == (int)l_lo(w) ? (int)l_hi(w) : (int)l_lo(w);
@@ -808,6 +852,9 @@ __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint
     t.unpack_regs(regs);
     if (lane == 0) { t.lds->cnt[sym] += 1u; }
     lds_fence();
+#ifdef SQZ_DEBUG_TREE
+    if (g_dbg_on && lane == 0) { printf("slow_changed sym=%d aux=%d depth=%d next=%d\n", sym, t.aux, t.depth, t.next); }
+#endif
     if (t.aux == 0 || t.depth + 4 >= kMaxFastDepth) {   // deep tree: one lane, explicit stacks
         t.aux = 0;
         if (lane == 0) { t.changed(sym); }
@@ -937,7 +984,13 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
     };
     // the tokens' own leaves (duplicates test the same node twice: harmless), then the internal nodes
     uint32_t na, nb;
+#ifdef SQZ_DEBUG_TREE
+    if (g_dbg_on && lane < 2) { printf("batch lane=%d m=%d a=%d b=%d qa=%u P64=%llx P8[qa]=%u P8[qa+1]=%u rng=%x cnt=%x\n", lane, m, a, b, qa, (unsigned long long)lds->P64[lane], (unsigned)lds->P8[qa], (unsigned)lds->P8[qa + 1], ra, lds->cnt[ia]); }
+#endif
     test(ia, has_a, na);
+#ifdef SQZ_DEBUG_TREE
+    if (g_dbg_on && lane < 1) { printf("batch after leaf test: na=%u ok=%d\n", na, ok); }
+#endif
     test(ib, has_b, nb);
     constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
     uint32_t nl[kLitRows], np;

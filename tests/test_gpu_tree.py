@@ -47,6 +47,18 @@ def device_tree(dev, n_ref, syms, batch):
     return which, d[:8], d[8:].reshape(nodes, 4)
 
 
+def first_bad_prefix(dev, n, syms, batch, limit=400):
+    """on a mismatch: the shortest prefix of the sequence whose device tree differs from the oracle's"""
+    for k in range(1, min(len(syms), limit) + 1):
+        arrs, info = O.tree_run(O.ORACLE, "sqzo_tree_run", n, syms[:k])
+        which, head, nodes = device_tree(dev, n, syms[:k], batch)
+        try:
+            compare(which, head, nodes, n, arrs, info)
+        except AssertionError as e:
+            return k, [int(x) for x in syms[max(0, k - 6):k]], str(e), [int(h) for h in head]
+    return None
+
+
 def rev_bits(path, bits):
     c = 0
     for k in range(bits):
@@ -134,7 +146,10 @@ def test_reference_tree_dumps(dev, batch):
             arrs, info = O.tree_run(O.ORACLE, "sqzo_tree_run", 32, syms)
             ref, n = arrs, 32
         which, head, nodes = device_tree(dev, n, syms, batch)
-        compare(which, head, nodes, n, ref, info)
+        try:
+            compare(which, head, nodes, n, ref, info)
+        except AssertionError as e:
+            raise AssertionError(f"{name} batch {batch}: {e}; first bad prefix: {first_bad_prefix(dev, n, syms, batch)}")
 
 
 def oracle_counters(n, syms):
@@ -163,4 +178,8 @@ def test_device_tree_vs_oracle(dev, batch):
     for n, syms in cases:
         arrs, info = O.tree_run(O.ORACLE, "sqzo_tree_run", n, syms)
         which, head, nodes = device_tree(dev, n, syms, batch)
-        compare(which, head, nodes, n, arrs, info, oracle_counters(n, syms))
+        try:
+            compare(which, head, nodes, n, arrs, info, oracle_counters(n, syms))
+        except AssertionError as e:
+            raise AssertionError(f"n={n} len={len(syms)} batch {batch}: {e}; first bad prefix: "
+                                 f"{first_bad_prefix(dev, n, syms, batch)}")
