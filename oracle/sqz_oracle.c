@@ -15,6 +15,14 @@
 #include <stdio.h>
 #include <math.h>
 
+/* huffman.h:228: the tree stops taking updates once its depth mark reaches 63.  No real stream gets
+ * there (a chain of depth d needs ~2^d symbols), so the tests that want to SEE the freeze build a
+ * variant of this file and of the kernels with a lower threshold (tests/test_emu.py); the pinned
+ * oracle always uses 63. */
+#ifndef SQZO_FREEZE_DEPTH
+#define SQZO_FREEZE_DEPTH 63
+#endif
+
 /* ------------------------------------------------------------------ */
 /* alphabet constants: squeeze.h:9-25                                  */
 enum {
@@ -338,7 +346,7 @@ static void tree_check(const tree* t) {
 static void tree_bump(tree* t, int32_t i) { /* huffman.h:218-235 */
     if (t->up[i] == -1) {
         (void)tree_insert(t, i);
-    } else if (!t->complete && t->depth < 63 &&
+    } else if (!t->complete && t->depth < SQZO_FREEZE_DEPTH &&
                t->freq[i] < UINT64_MAX - 1) {
         t->freq[i]++;
         tree_changed(t, i);

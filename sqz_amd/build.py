@@ -51,10 +51,39 @@ def build_native(force=False, verbose=True):
     return LIB
 
 
+# Device builds with LOWERED thresholds: the code paths no real stream reaches (a stream giving up its
+# leaf intervals at the token limit, trees too deep for one lane per level, the reference's freeze)
+# executed on the GPU and held against the oracle by tests/test_gpu_variants.py.  Test builds: nothing
+# loads them except that test (through SQZ_AMD_LIB).
+VARIANTS = {
+    "wide": ["-DSQZ_BATCH_TOKENS=1500"],
+    "shallow": ["-DSQZ_AUX_DEPTH=7", "-DSQZ_MAX_FAST_DEPTH=12"],
+    "freeze": ["-DSQZ_FREEZE_DEPTH=9"],
+}
+
+
+def variant_path(name):
+    return os.path.join(LIBDIR, f"libsqz_amd_{name}.so")
+
+
+def build_variants(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + PUBLIC
+    for name, flags in VARIANTS.items():
+        lib = variant_path(name)
+        if not force and not _stale(lib, deps):
+            continue
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fvisibility=hidden", *flags, "-I" + os.path.join(ROOT, "include"), "-o", lib] + srcs
+        if verbose:
+            print("[sqz_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+
 def build_oracle(verbose=True):
     """TEST INFRASTRUCTURE: the CPU restatement and, when possible, the reference."""
     odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["make", "-C", odir, "-s", "all"])
+    subprocess.check_call(["make", "-C", odir, "-s", "all", "freeze9"])
     if os.path.isdir("/root/reference/attic/map_experiment"):
         subprocess.check_call(["make", "-C", odir, "-s", "ref"])
     elif verbose:
@@ -63,4 +92,6 @@ def build_oracle(verbose=True):
 
 if __name__ == "__main__":
     build_native(force="--force" in sys.argv)
+    if "--variants" in sys.argv:
+        build_variants(force="--force" in sys.argv)
     build_oracle()

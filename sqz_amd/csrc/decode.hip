@@ -216,8 +216,12 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 else { __builtin_amdgcn_s_setprio(0); }
             }
         }
+        if (ntok > kBatchTokens && (lit.aux | pos.aux) != 0) {     // counts are about to outgrow their 24 bits
+            lit.give_up_aux(lane);
+            pos.give_up_aux(lane);
+        }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
-                            (lit.aux & pos.aux) == 0 || ntok > (1u << 24) - 256u;
+                            (lit.aux & pos.aux) == 0;
         if (lit.lut_ok == 0) { lit.build_lut(lane); }
         if (pos.lut_ok == 0) { pos.build_lut(lane); }
         // ---- read ahead with the trees held still: every lane decodes the token that would
@@ -311,7 +315,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             uint64_t starts = 0;
             uint32_t s = 0;
             do {
-                asm("s_bitset1_b64 %0, %1" : "+s"(starts) : "s"(s));      // starts |= 1 << s, one scalar op
+                set_bit64(starts, s);
                 s += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s);
             } while (s < (uint32_t)kWave);
             if (s >= 128u) {                                      // the last start is the refused one

@@ -163,9 +163,13 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
     const bool unseen = (c.levels == 0);                    // node[s].bits == 0
     if (unseen) { c = t.chain_up(nyt, lane); }
     const int leaf = unseen ? nyt : s;
-    uint64_t code = t.bump_wave(leaf, c, lane);             // code of the tree BEFORE the update
+    // the code of the tree BEFORE the update (squeeze.h:239-246): the ballot of the chain's hi/lo
+    // choices, or, for a chain longer than the wave holds, a walk -- made before the tree moves
     int width = c.levels;                                   // ballot bits beyond `levels` are 0
-    if (width >= kMaxFastDepth) { code = deep_code(t.lds->lnk, leaf, width); }
+    uint64_t deep = 0;
+    if (width >= kMaxFastDepth) { deep = deep_code(t.lds->lnk, leaf, width); }
+    uint64_t code = t.bump_wave(leaf, c, lane);
+    if (c.levels >= kMaxFastDepth) { code = deep; }
     q.push(code, width, lane);
     if (unseen) {
         q.push_lsb((uint32_t)(s - T::kBase), raw_bits, lane);
@@ -300,13 +304,17 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             bsym = kPosBase + pc.code;
         }
         // unseen symbols need the NYT escape + an insert: they end the step
-        const uint32_t da = valid ? c_d(lds.tree.cnt[a]) : 1u;
-        const uint32_t db = (valid && is_match) ? c_d(lds.tree.cnt[bsym]) : 1u;
-        const uint64_t unseen = __ballot(valid && (da == 0 || db == 0 || !wellformed));
+        const bool new_a = valid && l_up(lds.tree.lnk[a]) == kNil;
+        const bool new_b = valid && is_match && l_up(lds.tree.lnk[bsym]) == kNil;
+        const uint64_t unseen = __ballot(valid && (new_a || new_b || !wellformed));
         const uint64_t vmask = __ballot(valid);
         int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
+        if (cursor > kBatchTokens && (lit.aux | pos.aux) != 0) {  // counts are about to outgrow their 24 bits
+            lit.give_up_aux(lane);
+            pos.give_up_aux(lane);
+        }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
-                            (lit.aux & pos.aux) == 0 || cursor > (1u << 24) - 256u;
+                            (lit.aux & pos.aux) == 0;
         uint32_t ca = 0, cb = 0;
         int wa = 0, wb = 0;
         const int offered = m;
@@ -389,8 +397,8 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     }
     // leaf counts for huffman_entropy (huffman.h:237-249; the host does the logarithms)
     if (stats_out != nullptr) {
-        for (int k = lane; k < kLitLeaves; k += kWave) { stats_out[b].lit_freq[k] = c_f(lds.tree.cnt[k]); }
-        if (lane < kPosLeaves) { stats_out[b].pos_freq[lane] = c_f(lds.tree.cnt[kPosBase + lane]); }
+        for (int k = lane; k < kLitLeaves; k += kWave) { stats_out[b].lit_freq[k] = lit.freq(k); }
+        if (lane < kPosLeaves) { stats_out[b].pos_freq[lane] = pos.freq(kPosBase + lane); }
     }
 }
 
@@ -416,7 +424,7 @@ __device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, Em
         if (k + (uint32_t)lane < count) { sym = symbols[k + lane]; }
         const bool valid = sym >= 0 && sym < T::kLeaves && lane < batch;
         const int leaf = valid ? T::kBase + sym : T::kRoot;
-        const uint64_t seen = __ballot(valid && c_d(lds.tree.cnt[leaf]) != 0);
+        const uint64_t seen = __ballot(valid && l_up(lds.tree.lnk[leaf]) != kNil);
         int m = (~seen == 0ull) ? kWave : __builtin_ctzll(~seen);   // leading attached symbols (0..64)
         const bool frozen = t.complete != 0 || t.depth >= kFreezeDepth || t.aux == 0;
         uint32_t ca, cb; int wa, wb;

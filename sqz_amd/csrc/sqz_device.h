@@ -177,6 +177,16 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v) {
     return v;
 }
 
+// mask |= 1 << bit on a wave-uniform mask: one scalar op (tests/emu compiles these kernels for the
+// CPU wave emulator, which has no scalar unit)
+__device__ __forceinline__ void set_bit64(uint64_t& mask, uint32_t bit) {
+#ifdef SQZ_WAVE_EMU
+    mask |= 1ull << bit;
+#else
+    asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(bit));
+#endif
+}
+
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

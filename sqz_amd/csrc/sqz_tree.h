@@ -88,6 +88,10 @@ constexpr int kDepthShift = 24;
 #ifndef SQZ_FREEZE_DEPTH
 #define SQZ_FREEZE_DEPTH 63                   // huffman.h:228 `t->depth < 63`
 #endif
+#ifndef SQZ_BATCH_TOKENS
+#define SQZ_BATCH_TOKENS ((1u << 24) - 256u)  // a count word holds 24 bits while the intervals are kept
+#endif
+constexpr uint32_t kBatchTokens = SQZ_BATCH_TOKENS;
 constexpr int kAuxDepth = SQZ_AUX_DEPTH;
 constexpr int kMaxFastDepth = SQZ_MAX_FAST_DEPTH;
 constexpr int kFreezeDepth = SQZ_FREEZE_DEPTH;
@@ -203,9 +207,27 @@ struct Tree {
 
     __device__ __forceinline__ bool is_leaf(uint32_t v) const { return v < (uint32_t)kRoot; }
     __device__ __forceinline__ uint32_t up_of(int i) const { return l_up(lds->lnk[i]); }
-    __device__ __forceinline__ uint32_t freq(int i) const { return c_f(lds->cnt[i]); }
-    __device__ __forceinline__ void set_freq(int i, uint32_t f) { lds->cnt[i] = (lds->cnt[i] & ~kCountMask) | (f & kCountMask); }
+    // While a tree keeps its intervals (aux) a count word is count (24 bits) | depth << 24 and a stream
+    // has fewer than 2^24 tokens; once it has given them up (give_up_aux: a very deep tree, or the
+    // kernel's token limit) the word is the full 32-bit count and depths are worked out on demand.
+    __device__ __forceinline__ uint32_t freq(int i) const { const uint32_t w = lds->cnt[i]; return aux != 0 ? c_f(w) : w; }
+    __device__ __forceinline__ void set_freq(int i, uint32_t f) {
+        lds->cnt[i] = aux != 0 ? ((lds->cnt[i] & ~kCountMask) | (f & kCountMask)) : f;
+    }
     __device__ __forceinline__ void set_depth(int i, uint32_t d) { lds->cnt[i] = (lds->cnt[i] & kCountMask) | (d << kDepthShift); }
+    // depth of a node by walking up (wide mode has no stored depths)
+    __device__ __forceinline__ int depth_by_walk(int v) const {
+        int d = 0;
+        for (uint32_t a = l_up(lds->lnk[v]); a != kNil && d < kStack; a = l_up(lds->lnk[a])) { d++; }
+        return d;
+    }
+    // leave the interval machinery for good: counts become full words (the depth bits go)
+    __device__ __forceinline__ void give_up_aux(int lane) {
+        if (aux == 0) { return; }
+        aux = 0;
+        for (int v = BASE + lane; v < BASE + NODES; v += kWave) { lds->cnt[v] &= kCountMask; }
+        lds_fence();
+    }
     __device__ __forceinline__ int code_slot(int leaf) const { return leaf - BASE + POS0; }
 
     // registers <-> one word: next:10 | depth:8 | complete | fault | aux ; bit 31 = the call's own result
@@ -225,9 +247,9 @@ struct Tree {
         aux = __builtin_amdgcn_readfirstlane(aux);
     }
     // the reference's high-water mark moved: a tree this deep gives up the interval machinery
-    __device__ __forceinline__ void raise_mark(int d) {
+    __device__ __forceinline__ void raise_mark(int d, int lane) {
         if (d > depth) { depth = d; }
-        if (depth >= kAuxDepth) { aux = 0; }
+        if (depth >= kAuxDepth) { give_up_aux(lane); }
     }
 
     // ---------------- flat passes: one lane per node ----------------------------------------
@@ -244,7 +266,7 @@ struct Tree {
             visited += in ? 1u : 0u;
         }
         if (top == kRoot) { depth = 0; }
-        raise_mark((int)wave_max(deepest));
+        raise_mark((int)wave_max(deepest), lane);
         stats.updates += wave_sum(visited);                    // huffman.h:42, one per node visited
     }
 
@@ -317,7 +339,7 @@ struct Tree {
         lds_fence();
         fix_partners(p, 1, lane);
         if (p == kRoot) { depth = 0; }
-        raise_mark((int)wave_max(deepest));
+        raise_mark((int)wave_max(deepest), lane);
         stats.updates += wave_sum(visited) - (kWave - 1);      // every lane started at 1 for p itself
     }
 
@@ -381,34 +403,28 @@ struct Tree {
         set_freq(i, a + b);
     }
 
-    // huffman.h:41-62 by a walk: depths below `top`, the mark, the statistics
+    // huffman.h:41-62 by a walk (wide mode only: no stored depths): the mark and the statistics.  A
+    // stack entry is node | depth << 10.
     __device__ __forceinline__ void relabel(int top) {
         if (top == kRoot) { depth = 0; }
         int sp = 0;
-        lds->lvl[sp++] = (uint16_t)top;
+        lds->lvl[sp++] = (uint16_t)((uint32_t)top | ((uint32_t)depth_by_walk(top) << 10));
         for (int guard = 0; sp > 0; guard++) {
             if (guard >= NODES) { fault = 1; break; }            // more visits than nodes: the links are corrupt
-            const int v = lds->lvl[--sp];
-            const uint32_t w = lds->lnk[v];
-            const int b = (int)c_d(lds->cnt[v]);
+            const uint32_t e = lds->lvl[--sp];
+            const int v = (int)(e & 0x3FFu), b = (int)(e >> 10);
             stats.updates += 1;
             if (b > depth) { depth = b; }
-            if (b >= 62) { fault = 1; continue; }               // the depth field holds 6 bits; reference asserts bits < 63
+            if (v < kRoot) { continue; }
+            if (b >= 62) { fault = 1; continue; }               // reference asserts bits < 63
+            const uint32_t w = lds->lnk[v];
             const uint32_t kids[2] = { l_hi(w), l_lo(w) };
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const uint32_t ch = kids[j];
-                if (ch == kNil) { continue; }
-                set_depth((int)ch, (uint32_t)(b + 1));
-                if (ch >= (uint32_t)kRoot) {
-                    if (sp < kStack) { lds->lvl[sp++] = (uint16_t)ch; } else { fault = 1; }
-                } else {
-                    stats.updates += 1;
-                    if (b + 1 > depth) { depth = b + 1; }
-                }
+                if (kids[j] == kNil) { continue; }
+                if (sp < kStack) { lds->lvl[sp++] = (uint16_t)(kids[j] | ((uint32_t)(b + 1) << 10)); } else { fault = 1; }
             }
         }
-        if (depth >= kAuxDepth) { aux = 0; }
     }
 
     __device__ __forceinline__ int order_pair(int i) {         // huffman.h:64-86, one lane
@@ -474,10 +490,10 @@ struct Tree {
     // its interval holds the leaf's position, and its depth says which lane it belongs to -- one
     // flat pass and a trip through LDS instead of one dependent read per level.
     __device__ __forceinline__ Chain chain_up(int s, int lane) const {
-        const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[s]);
-        const int levels = (int)c_d(sc);
+        int levels = 0;
         int mine = (int)kNil;
         if (aux != 0) {
+            levels = (int)c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[s]));
             const uint32_t q = r_st((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[s]));
             for (int v = kRoot + lane; v < next; v += kWave) {
                 const uint32_t w = lds->rng[v];
@@ -490,13 +506,17 @@ struct Tree {
             mine = lane <= levels ? (int)lds->lvl[lane] : (int)kNil;
             lds_fence();
         } else {
-            const int stop = levels < kMaxFastDepth ? levels : kMaxFastDepth;
+            // no stored depths: one dependent read per level, counting them
             int a = s;
             mine = lane == 0 ? s : mine;
-            for (int k = 1; k <= stop; k++) {
+            levels = 0;
+            for (int k = 1; k <= kMaxFastDepth; k++) {
                 a = __builtin_amdgcn_readfirstlane((int)l_up(lds->lnk[a]));
+                if (a == (int)kNil) { break; }
                 mine = lane == k ? a : mine;
+                levels = k;
             }
+            if (levels == kMaxFastDepth && l_up(lds->lnk[a]) != kNil) { levels = depth_by_walk(s); }   // longer than the wave covers
         }
 #ifdef SQZ_DEBUG_TREE
         if (g_dbg_on && lane < 6) { printf("chain_up s=%d lane=%d levels=%d mine=%d aux=%d next=%d\n", s, lane, levels, mine, aux, next); }
@@ -554,7 +574,7 @@ struct Tree {
 #endif
         if (c.active) {
             // the parent sits levels - lane - 1 below the root
-            lds->cnt[p] = ((f0 + incl) & kCountMask) | ((uint32_t)(levels - lane - 1) << kDepthShift);
+            lds->cnt[p] = aux != 0 ? (((f0 + incl) & kCountMask) | ((uint32_t)(levels - lane - 1) << kDepthShift)) : (f0 + incl);
             if (swap) { lds->lnk[p] = mk_lnk(l_up(pw), l_hi(pw), l_lo(pw)); }
             lds->pend[sp + lane] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
         }
@@ -637,7 +657,7 @@ struct Tree {
         const int i_mine = c.holds ? c.mine : kRoot;
         const int i_par = c.active ? c.par : kRoot;
         const uint32_t cw = lds->cnt[i_mine];
-        const uint32_t fc = c_f(cw);
+        const uint32_t fc = aux != 0 ? c_f(cw) : cw;
         const uint32_t pw = lds->lnk[i_par];
         const bool is_hi = c.active & (l_hi(pw) == (uint32_t)c.mine);
         const uint64_t code_bits = __ballot(is_hi);
@@ -737,10 +757,9 @@ struct Tree {
                 lds->lnk[leaf] = mk_lnk((uint32_t)at, kNil, kNil);
                 set_freq(at, freq(at) + 1u);
                 // the tree is tiny (at IS the root: a split always makes two children): rebuild its aux by hand
-                const uint32_t d = c_d(lds->cnt[at]) + 1u;
-                set_depth(leaf, d);
                 const uint32_t w2 = lds->lnk[at];
-                const uint32_t lo = l_lo(w2), hi = l_hi(w2);
+                const uint32_t lo = aux != 0 ? l_lo(w2) : kNil, hi = aux != 0 ? l_hi(w2) : kNil;
+                if (aux != 0) { set_depth(leaf, c_d(lds->cnt[at]) + 1u); }
                 uint32_t pos = (uint32_t)POS0;
                 if (lo != kNil) {
                     lds->rng[lo] = mk_rng(pos, pos + 1, hi);           // a lo child is tested against its sibling
@@ -752,7 +771,7 @@ struct Tree {
                     if (CODES) { code[code_slot((int)hi)] = 1u; }
                     pos++;
                 }
-                lds->rng[at] = mk_rng((uint32_t)POS0, pos, kNil);
+                if (aux != 0) { lds->rng[at] = mk_rng((uint32_t)POS0, pos, kNil); }
             } else if (next >= kIdEnd) {                               // :180-182
                 ok = 0;
                 complete = 1;
@@ -769,8 +788,10 @@ struct Tree {
                                                            : mk_lnk(l_up(bw), l_lo(bw), (uint32_t)fresh);
                 lds->lnk[at] = mk_lnk((uint32_t)fresh, kNil, kNil);
                 lds->lnk[leaf] = mk_lnk((uint32_t)fresh, kNil, kNil);
-                lds->cnt[at] = acw + (1u << kDepthShift);
-                lds->cnt[leaf] = 1u | ((c_d(acw) + 1u) << kDepthShift);
+                if (aux != 0) {                                        // both children one level below at's old place
+                    lds->cnt[at] = acw + (1u << kDepthShift);
+                    lds->cnt[leaf] = 1u | ((c_d(acw) + 1u) << kDepthShift);
+                }
                 sum(fresh);
                 at = fresh;
             }
@@ -819,8 +840,8 @@ struct Tree {
                 swap_fix(at, lane);
             }
         }
-        if (aux == 0 || depth + 4 >= kMaxFastDepth) {                  // deep tree: the reference sequence on one lane
-            aux = 0;
+        if (depth + 4 >= kMaxFastDepth) {                              // chains longer than the wave: the reference sequence on one lane
+            give_up_aux(lane);
             if (lane == 0) { changed(start); relabel(at); }
             uniform_regs();
             lds_fence();
@@ -855,8 +876,8 @@ __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint
 #ifdef SQZ_DEBUG_TREE
     if (g_dbg_on && lane == 0) { printf("slow_changed sym=%d aux=%d depth=%d next=%d\n", sym, t.aux, t.depth, t.next); }
 #endif
-    if (t.aux == 0 || t.depth + 4 >= kMaxFastDepth) {   // deep tree: one lane, explicit stacks
-        t.aux = 0;
+    if (t.depth + 4 >= kMaxFastDepth) {                 // chains longer than the wave: one lane, explicit stacks
+        t.give_up_aux(lane);
         if (lane == 0) { t.changed(sym); }
         t.uniform_regs();
         lds_fence();

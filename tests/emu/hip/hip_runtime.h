@@ -17,6 +17,7 @@
  * Only what these kernels use is provided.
  */
 #pragma once
+#define SQZ_WAVE_EMU 1
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
