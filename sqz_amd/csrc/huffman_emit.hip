@@ -416,10 +416,6 @@ __device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, Em
     uint32_t k = 0;
     for (uint32_t step = 0; k < count && t.fault == 0 && (max_steps == 0 || step < max_steps); step++) {
         if (stop_early && t.aux == 0) { break; }               // (bisecting: do not crawl on after the intervals are lost)
-#ifdef SQZ_DEBUG_TREE
-        g_dbg_on = (k + 8 >= count) ? 1 : 0;
-        if (g_dbg_on && lane == 0) { printf("drive k=%u\n", k); }
-#endif
         int sym = -1;
         if (k + (uint32_t)lane < count) { sym = symbols[k + lane]; }
         const bool valid = sym >= 0 && sym < T::kLeaves && lane < batch;

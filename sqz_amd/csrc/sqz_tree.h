@@ -101,16 +101,12 @@ constexpr int kTokenBits = 2 * (kAuxDepth - 1) + 18;
 constexpr int kPackWords = (63 + 58 + kWave * kTokenBits + 63) / 64 + 1;     // carry + pending + 64 tokens
 constexpr int kImageWords = kPackWords > kWave ? kPackWords : kWave;         // (the histogram takes 64 words)
 
-#ifdef SQZ_DEBUG_TREE
-__device__ int g_dbg_on = 0;      // development tracing: only while this is set
-#endif
-
 struct TreeLds {
     uint32_t lnk[kAllNodes];
     uint32_t rng[kAllNodes];
     uint32_t cnt[kAllNodes];
     uint32_t pend[kWave];                     // parent << 16 | child, one per pending level
-    uint16_t lvl[kStack];                     // chain scatter / the one-lane path's stack
+    uint16_t lvl[kStack];                     // the one-lane path's stack
     // one batch: histogram over leaf positions (a byte each), turned into its prefix sums in place
     // (the first 64 words); the encoder's bit image of a step lives here too, after the update
     union { uint64_t P64[kImageWords]; uint32_t P32[2 * kImageWords]; uint8_t P8[8 * kImageWords]; };
@@ -134,10 +130,12 @@ __device__ __forceinline__ uint32_t l_up(uint32_t w) { return w & 0x3FFu; }
 __device__ __forceinline__ uint32_t l_lo(uint32_t w) { return (w >> 10) & 0x3FFu; }
 __device__ __forceinline__ uint32_t l_hi(uint32_t w) { return (w >> 20) & 0x3FFu; }
 __device__ __forceinline__ uint32_t mk_lnk(uint32_t up, uint32_t lo, uint32_t hi) { return up | (lo << 10) | (hi << 20); }
-__device__ __forceinline__ uint32_t r_st(uint32_t w) { return w & 0x1FFu; }
-__device__ __forceinline__ uint32_t r_en(uint32_t w) { return (w >> 9) & 0x1FFu; }
-__device__ __forceinline__ uint32_t r_pa(uint32_t w) { return (w >> 18) & 0x3FFu; }
-__device__ __forceinline__ uint32_t mk_rng(uint32_t st, uint32_t en, uint32_t pa) { return st | (en << 9) | (pa << 18); }
+// rng word: a leaf's position (low 9 bits), an internal node's first | last << 10 leaf; the partner on top
+__device__ __forceinline__ uint32_t r_pos(uint32_t w) { return w & 0x1FFu; }
+__device__ __forceinline__ uint32_t r_first(uint32_t w) { return w & 0x3FFu; }
+__device__ __forceinline__ uint32_t r_last(uint32_t w) { return (w >> 10) & 0x3FFu; }
+__device__ __forceinline__ uint32_t r_pa(uint32_t w) { return (w >> 20) & 0x3FFu; }
+constexpr uint32_t kEndsMask = 0xFFFFFu;      // everything below the partner
 __device__ __forceinline__ uint32_t c_f(uint32_t w) { return w & kCountMask; }
 __device__ __forceinline__ uint32_t c_d(uint32_t w) { return (w >> kDepthShift) & 0x3Fu; }
 
@@ -157,7 +155,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // one lane's share of a root path: its node and that node's parent
 struct Chain {
     int mine, par;
-    int levels;        // uniform: edges between leaf and root
+    int levels;        // uniform: edges between the start node and the root
     bool holds;        // this lane holds a node of the path
     bool active;       // ... and the node has a parent
     bool has_g;        // ... and that parent is not the root
@@ -166,7 +164,7 @@ struct Chain {
 // The slow paths live in real (non-inlined) functions so that the per-step loop of the kernels
 // stays small (I-cache).  State crosses the call as plain values.
 template <class T> __device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
-template <class T> __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
+template <class T> __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane);
 template <class T> __device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane);
 
 // BASE: first node id; LEAVES / NODES: id space (leaves keep their symbol value + BASE, internal
@@ -184,7 +182,7 @@ struct Tree {
     int depth;          // huffman.h:26 high-water mark
     int complete;       // huffman.h:27
     int fault;          // stack / depth guard (never set for realistic streams)
-    int aux;            // intervals / partners / codes are kept (tree shallower than kAuxDepth so far)
+    int aux;            // leaf positions / ends / partners / codes are kept (tree shallower than kAuxDepth so far)
     int lut_ok;         // decoder: the lookup table matches the tree
     TreeStats stats;
 
@@ -194,11 +192,12 @@ struct Tree {
     static constexpr int kLutBits = LUT_BITS;
     static constexpr int kIdEnd = BASE + ((LEAVES + 1 + REF_LEAVES - 2) < NODES ? (LEAVES + 1 + REF_LEAVES - 2) : NODES);
     static constexpr bool kCodes = CODES;
+    static constexpr int kLeafRows = (LEAVES + kWave - 1) / kWave;
 
     __device__ __forceinline__ void init_all(int lane) {      // huffman.h:251-269
         for (int i = BASE + lane; i < BASE + NODES; i += kWave) {
             lds->lnk[i] = 0x3FFFFFFFu;
-            lds->rng[i] = mk_rng(0, 0, kNil);
+            lds->rng[i] = kNil << 20;
             lds->cnt[i] = 0;
         }
         next = kRoot + 1; depth = 0; complete = 0; fault = 0; aux = 1; lut_ok = 0;
@@ -207,21 +206,20 @@ struct Tree {
 
     __device__ __forceinline__ bool is_leaf(uint32_t v) const { return v < (uint32_t)kRoot; }
     __device__ __forceinline__ uint32_t up_of(int i) const { return l_up(lds->lnk[i]); }
-    // While a tree keeps its intervals (aux) a count word is count (24 bits) | depth << 24 and a stream
-    // has fewer than 2^24 tokens; once it has given them up (give_up_aux: a very deep tree, or the
-    // kernel's token limit) the word is the full 32-bit count and depths are worked out on demand.
+    // While a tree keeps its positions (aux) a count word is count (24 bits) | depth << 24 (the
+    // depth of leaves only; internal nodes keep none) and a stream has fewer than 2^24 tokens; once it
+    // has given them up (give_up_aux: a very deep tree, or the kernel's token limit) the word is the
+    // full 32-bit count and depths are worked out on demand.
     __device__ __forceinline__ uint32_t freq(int i) const { const uint32_t w = lds->cnt[i]; return aux != 0 ? c_f(w) : w; }
     __device__ __forceinline__ void set_freq(int i, uint32_t f) {
         lds->cnt[i] = aux != 0 ? ((lds->cnt[i] & ~kCountMask) | (f & kCountMask)) : f;
     }
-    __device__ __forceinline__ void set_depth(int i, uint32_t d) { lds->cnt[i] = (lds->cnt[i] & kCountMask) | (d << kDepthShift); }
-    // depth of a node by walking up (wide mode has no stored depths)
     __device__ __forceinline__ int depth_by_walk(int v) const {
         int d = 0;
         for (uint32_t a = l_up(lds->lnk[v]); a != kNil && d < kStack; a = l_up(lds->lnk[a])) { d++; }
         return d;
     }
-    // leave the interval machinery for good: counts become full words (the depth bits go)
+    // leave the position machinery for good: counts become full words (the depth bits go)
     __device__ __forceinline__ void give_up_aux(int lane) {
         if (aux == 0) { return; }
         aux = 0;
@@ -229,6 +227,13 @@ struct Tree {
         lds_fence();
     }
     __device__ __forceinline__ int code_slot(int leaf) const { return leaf - BASE + POS0; }
+    // first / last leaf below a node, position of a leaf
+    __device__ __forceinline__ uint32_t first_leaf(uint32_t v) const { return is_leaf(v) ? v : r_first(lds->rng[v]); }
+    __device__ __forceinline__ uint32_t last_leaf(uint32_t v) const { return is_leaf(v) ? v : r_last(lds->rng[v]); }
+    __device__ __forceinline__ uint32_t pos_of(uint32_t leaf) const { return r_pos(lds->rng[leaf]); }
+    __device__ __forceinline__ void set_ends(int v, uint32_t first, uint32_t last) {
+        lds->rng[v] = (lds->rng[v] & ~kEndsMask) | first | (last << 10);
+    }
 
     // registers <-> one word: next:10 | depth:8 | complete | fault | aux ; bit 31 = the call's own result
     __device__ __forceinline__ uint32_t pack_regs() const {
@@ -246,28 +251,40 @@ struct Tree {
         fault = __builtin_amdgcn_readfirstlane(fault);
         aux = __builtin_amdgcn_readfirstlane(aux);
     }
-    // the reference's high-water mark moved: a tree this deep gives up the interval machinery
+    // the reference's high-water mark moved: a tree this deep gives up the position machinery
     __device__ __forceinline__ void raise_mark(int d, int lane) {
         if (d > depth) { depth = d; }
         if (depth >= kAuxDepth) { give_up_aux(lane); }
     }
 
-    // ---------------- flat passes: one lane per node ----------------------------------------
+    // ---------------- passes over the leaves: one lane per leaf --------------------------------
     // The depth mark as huffman_update_paths(top) leaves it (huffman.h:44,61): reset when top is
-    // the root, then the deepest node of top's subtree.  Subtree = interval containment + deeper.
-    __device__ __forceinline__ void mark_subtree(int top, int lane) {
-        const uint32_t tr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[top]);
-        const uint32_t a = r_st(tr), b = r_en(tr), dt = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[top]));
-        uint32_t deepest = dt, visited = 0;
-        for (int v = BASE + lane; v < next; v += kWave) {
-            const uint32_t w = lds->rng[v], d = c_d(lds->cnt[v]);
-            const bool in = r_en(w) > r_st(w) && r_st(w) >= a && r_en(w) <= b && (v == top || d > dt);
-            deepest = (in && d > deepest) ? d : deepest;
-            visited += in ? 1u : 0u;
+    // the root, then the deepest node of top's subtree -- always a leaf, one of those at positions
+    // [a, b).  The walk visits every node of the subtree once (huffman.h:42): 2 * leaves - 1 of them.
+    __device__ __forceinline__ void mark_range(int top, uint32_t a, uint32_t b, uint32_t deepest_known, int lane) {
+        uint32_t deepest = deepest_known;
+        if (deepest_known == 0) {
+#pragma unroll
+            for (int r = 0; r < kLeafRows; r++) {
+                const int v = BASE + r * kWave + lane;
+                const uint32_t d = c_d(lds->cnt[v < kRoot ? v : kRoot]);
+                const uint32_t q = r_pos(lds->rng[v < kRoot ? v : kRoot]);
+                const bool in = v < kRoot && d != 0 && q >= a && q < b;
+                deepest = (in && d > deepest) ? d : deepest;
+            }
+            deepest = wave_max(deepest);
         }
+#ifdef SQZ_DEBUG_TREE
+        if (lane == 0) { printf("relabel visited=%u top=%d [%u,%u)\n", 2u * (b - a) - 1u, top, a, b); }
+#endif
         if (top == kRoot) { depth = 0; }
-        raise_mark((int)wave_max(deepest), lane);
-        stats.updates += wave_sum(visited);                    // huffman.h:42, one per node visited
+        raise_mark((int)deepest, lane);
+        stats.updates += 2u * (b - a) - ((uint32_t)top == (uint32_t)kRoot && l_lo(lds->lnk[kRoot]) == kNil ? 0u : 1u);
+    }
+    __device__ __forceinline__ void mark_subtree(int top, int lane) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(first_leaf((uint32_t)top)));
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(last_leaf((uint32_t)top))) + 1u;
+        mark_range(top, a, b, 0u, lane);
     }
 
     // test partners of the nodes up to `levels` levels below `top` (they are the only ones whose
@@ -296,87 +313,92 @@ struct Tree {
                 const uint32_t gw = lds->lnk[l_up(pw)];
                 pa = l_lo(gw) == p ? l_hi(gw) : l_lo(gw);
             }
-            lds->rng[v] = (lds->rng[v] & 0x3FFFFu) | (pa << 18);
+            lds->rng[v] = (lds->rng[v] & kEndsMask) | (pa << 20);
         }
         lds_fence();
     }
 
-    // the two children of p have traded slots (the links already say so): X = the child now in the
-    // lo slot (its interval [m, b) comes first from now on), Y = the child now hi (was [a, m)).
-    // Positions move, one code bit of every leaf below p flips, X and Y trade tests; the depth mark
-    // and the statistics see the walk huffman_swap_siblings makes (huffman.h:76-80).
-    __device__ __forceinline__ void swap_fix(int p, int lane) {
+    // The two children of p have traded slots (the links already say so): X = the child now in the
+    // lo slot (its leaves, positions [m, b), come first from now on), Y = the child now hi (was
+    // [a, m)).  Leaf positions move, one code bit of every leaf below p flips, p's ends and the
+    // tests of X and Y follow; the depth mark and the statistics see the walk
+    // huffman_swap_siblings makes (huffman.h:76-80).  dp = depth of p.
+    __device__ __forceinline__ void swap_fix(int p, uint32_t dp, int lane) {
         stats.swaps += 1;
-        if (aux == 0) {                                        // deep tree: the reference's walk, one lane
+        if (aux == 0) {                                        // wide mode: the reference's walk, one lane
             if (lane == 0) { relabel(p); }
             uniform_regs();
             lds_fence();
             return;
         }
-#ifdef SQZ_DEBUG_TREE
-        if (g_dbg_on && lane == 0) { printf("swap_fix p=%d lnk=%x\n", p, lds->lnk[p]); }
-#endif
-        // (read by one lane and broadcast: the pass below rewrites these very words)
+        // (read by one lane and broadcast: the pass below rewrites positions)
         const uint32_t pw = lds->lnk[p];
-        const uint32_t xr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[l_lo(pw)]);
-        const uint32_t yr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[l_hi(pw)]);
-        const uint32_t a = r_st(yr), m = r_st(xr), b = r_en(xr);
-        const uint32_t dp = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[p]));
-        uint32_t deepest = dp, visited = 1;
-        for (int v = BASE + lane; v < next; v += kWave) {
-            const uint32_t w = lds->rng[v];
-            const uint32_t s = r_st(w), e = r_en(w);
-            const bool in_x = e > s && s >= m && e <= b, in_y = e > s && s >= a && e <= m;
+        const uint32_t X = l_lo(pw), Y = l_hi(pw);
+        const uint32_t fX = first_leaf(X), lX = last_leaf(X), fY = first_leaf(Y), lY = last_leaf(Y);
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fY));
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fX));
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lX)) + 1u;
+#ifdef SQZ_DEBUG_TREE
+        if (lane == 0) { printf("swap p=%d dp=%u X=%u Y=%u a=%u m=%u b=%u\n", p, dp, X, Y, a, m, b); }
+#endif
+        uint32_t deepest = 0;
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (BASE + r * kWave >= kRoot) { break; }
+            const int vv = v < kRoot ? v : kRoot;
+            const uint32_t w = lds->rng[vv], d = c_d(lds->cnt[vv]);
+            const uint32_t q = r_pos(w);
+            const bool live = v < kRoot && d != 0;
+            const bool in_x = live && q >= m && q < b, in_y = live && q >= a && q < m;
             if (in_x | in_y) {
-                const uint32_t d = c_d(lds->cnt[v]);
-                const uint32_t ns = in_x ? s - (m - a) : s + (b - m);
-                lds->rng[v] = (w & ~0x3FFFFu) | ns | ((ns + (e - s)) << 9);
-                if (CODES && is_leaf((uint32_t)v)) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
+                lds->rng[v] = (w & ~0x1FFu) | (in_x ? q - (m - a) : q + (b - m));
+                if (CODES) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
                 deepest = d > deepest ? d : deepest;
-                visited += 1;
             }
         }
+        if (lane == 0) { set_ends(p, fX, lY); }
         lds_fence();
         fix_partners(p, 1, lane);
-        if (p == kRoot) { depth = 0; }
-        raise_mark((int)wave_max(deepest), lane);
-        stats.updates += wave_sum(visited) - (kWave - 1);      // every lane started at 1 for p itself
+        mark_range(p, a, b, wave_max(deepest), lane);
     }
 
     // c (hi child of p) and its uncle u have traded places under g (the links already say so):
     //   left  (p = lo(g)):  [x][c][u] -> [x][u][c]      c: G01S -> G1S     u: G1S -> G01S
     //   right (p = hi(g)):  [u][x][c] -> [c][x][u]      c: G11S -> G0S     u: G0S -> G11S
-    // (G = the code of g, S = what follows below the moved node).  c's subtree comes up a level.
-    __device__ __forceinline__ void promote_fix(int g, int p, int c, int u, int left, int lane) {
+    // (G = the code of g, dg bits; S = what follows below the moved node).  c's leaves come up a level.
+    __device__ __forceinline__ void promote_fix(int g, uint32_t dg, int p, int c, int u, int left, int lane) {
         stats.moves += 1;
         if (aux == 0) { return; }
-#ifdef SQZ_DEBUG_TREE
-        if (g_dbg_on && lane == 0) { printf("promote_fix g=%d p=%d c=%d u=%d left=%d rng c=%x u=%x\n", g, p, c, u, left, lds->rng[c], lds->rng[u]); }
-#endif
-        // (read by one lane and broadcast: the pass below rewrites these very words)
         const uint32_t x = l_lo(lds->lnk[p]);
-        const uint32_t cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[c]);
-        const uint32_t ur = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[u]);
-        const uint32_t xr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[x]);
-        const uint32_t ca = r_st(cr), cb = r_en(cr), ua = r_st(ur), ub = r_en(ur), xa = r_st(xr), xb = r_en(xr);
+        const uint32_t fc = first_leaf((uint32_t)c), lc = last_leaf((uint32_t)c), fu = first_leaf((uint32_t)u);
+        const uint32_t lu = last_leaf((uint32_t)u), fx = first_leaf(x), lx = last_leaf(x);
+        const uint32_t ca = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fc));
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lc)) + 1u;
+        const uint32_t ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fu));
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lu)) + 1u;
+        const uint32_t xa = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fx));
+        const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lx)) + 1u;
+#ifdef SQZ_DEBUG_TREE
+        if (lane == 0) { printf("promote g=%d dg=%u p=%d c=%d u=%d x=%u left=%d c[%u,%u) u[%u,%u) x[%u,%u)\n", g, dg, p, c, u, x, left, ca, cb, ua, ub, xa, xb); }
+#endif
         const int C = (int)(cb - ca), U = (int)(ub - ua), X = (int)(xb - xa);
-        const uint32_t dg = c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[g]));
         const int dc = left ? U : -(U + X), du = left ? -C : C + X, dx = left ? 0 : C - U;
-        for (int v = BASE + lane; v < next; v += kWave) {
-            const uint32_t w = lds->rng[v];
-            const uint32_t s = r_st(w), e = r_en(w);
-            const bool live = e > s && v != p && v != g;
-            const bool in_c = live && s >= ca && e <= cb, in_u = live && s >= ua && e <= ub;
-            const bool in_x = live && s >= xa && e <= xb;
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (BASE + r * kWave >= kRoot) { break; }
+            const int vv = v < kRoot ? v : kRoot;
+            const uint32_t w = lds->rng[vv], cw = lds->cnt[vv];
+            const uint32_t q = r_pos(w), d = c_d(cw);
+            const bool live = v < kRoot && d != 0;
+            const bool in_c = live && q >= ca && q < cb, in_u = live && q >= ua && q < ub, in_x = live && q >= xa && q < xb;
             if (in_c | in_u | in_x) {
                 const int shift = in_c ? dc : in_u ? du : dx;
-                const uint32_t ns = (uint32_t)((int)s + shift);
-                lds->rng[v] = (w & ~0x3FFFFu) | ns | ((ns + (e - s)) << 9);
+                lds->rng[v] = (w & ~0x1FFu) | (uint32_t)((int)q + shift);
                 if (in_c | in_u) {
-                    const uint32_t cw = lds->cnt[v];
-                    const uint32_t d = c_d(cw);
                     lds->cnt[v] = in_c ? cw - (1u << kDepthShift) : cw + (1u << kDepthShift);
-                    if (CODES && is_leaf((uint32_t)v)) {
+                    if (CODES) {
                         const uint32_t old = code[code_slot(v)];
                         const uint32_t ls = in_c ? d - dg - 2u : d - dg - 1u;      // bits below the moved node
                         const uint32_t G = dg != 0 ? old >> (d - dg) : 0u;
@@ -387,15 +409,15 @@ struct Tree {
                 }
             }
         }
-        if (lane == 0) {                                       // p now holds x and u
-            const uint32_t ps = left ? xa : (uint32_t)((int)xa + dx);
-            lds->rng[p] = (lds->rng[p] & ~0x3FFFFu) | ps | ((ps + (uint32_t)(X + U)) << 9);
+        if (lane == 0) {                                       // p now holds x and u; g's ends follow its new children
+            set_ends(p, fx, lu);
+            if (left) { set_ends(g, fx, lc); } else { set_ends(g, fc, lu); }
         }
         lds_fence();
         fix_partners(g, 3, lane);
     }
 
-    // ---------------- the reference sequence on one lane (deep trees only) --------------------
+    // ---------------- the reference sequence on one lane (wide mode / deep trees) ----------------
     __device__ __forceinline__ void sum(int i) {               // huffman.h:90-96
         const uint32_t w = lds->lnk[i];
         const uint32_t a = l_lo(w) != kNil ? freq((int)l_lo(w)) : 0u;
@@ -456,7 +478,7 @@ struct Tree {
     }
 
     // huffman.h:130-147 with move_up (:98-128) inlined; LIFO order equals the reference's
-    // recursion order because both inner calls are tail calls.  One lane, aux already given up.
+    // recursion order because both inner calls are tail calls.  One lane, positions already given up.
     __device__ __forceinline__ void changed(int start) {
         int sp = climb(start, 0);
         for (int guard = 0; sp > 0; guard++) {
@@ -485,42 +507,21 @@ struct Tree {
         }
     }
 
-    // ---------------- a leaf's root path, one level per lane --------------------------------
-    // lane k receives level k (0 = the leaf).  With intervals: an internal node is an ancestor iff
-    // its interval holds the leaf's position, and its depth says which lane it belongs to -- one
-    // flat pass and a trip through LDS instead of one dependent read per level.
+    // ---------------- a node's root path, one level per lane -------------------------------------
+    // lane k receives level k (0 = the start node): one dependent read per level.
     __device__ __forceinline__ Chain chain_up(int s, int lane) const {
-        int levels = 0;
-        int mine = (int)kNil;
-        if (aux != 0) {
-            levels = (int)c_d((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->cnt[s]));
-            const uint32_t q = r_st((uint32_t)__builtin_amdgcn_readfirstlane((int)lds->rng[s]));
-            for (int v = kRoot + lane; v < next; v += kWave) {
-                const uint32_t w = lds->rng[v];
-                const int d = (int)c_d(lds->cnt[v]);
-                // (a node below s on its lo edge holds q as well: only the shallower ones are ancestors)
-                if (r_st(w) <= q && q < r_en(w) && d < levels) { lds->lvl[levels - d] = (uint16_t)v; }
-            }
-            if (lane == 0) { lds->lvl[0] = (uint16_t)s; }
-            lds_fence();
-            mine = lane <= levels ? (int)lds->lvl[lane] : (int)kNil;
-            lds_fence();
-        } else {
-            // no stored depths: one dependent read per level, counting them
-            int a = s;
-            mine = lane == 0 ? s : mine;
-            levels = 0;
-            for (int k = 1; k <= kMaxFastDepth; k++) {
-                a = __builtin_amdgcn_readfirstlane((int)l_up(lds->lnk[a]));
-                if (a == (int)kNil) { break; }
-                mine = lane == k ? a : mine;
-                levels = k;
-            }
-            if (levels == kMaxFastDepth && l_up(lds->lnk[a]) != kNil) { levels = depth_by_walk(s); }   // longer than the wave covers
+        int a = s, levels = 0;
+        int mine = lane == 0 ? s : (int)kNil;
+        for (int k = 1; k <= kMaxFastDepth; k++) {
+            a = __builtin_amdgcn_readfirstlane((int)l_up(lds->lnk[a]));
+            if (a == (int)kNil) { break; }
+            mine = lane == k ? a : mine;
+            levels = k;
         }
-#ifdef SQZ_DEBUG_TREE
-        if (g_dbg_on && lane < 6) { printf("chain_up s=%d lane=%d levels=%d mine=%d aux=%d next=%d\n", s, lane, levels, mine, aux, next); }
-#endif
+        if (levels == kMaxFastDepth && l_up(lds->lnk[a == (int)kNil ? s : a]) != kNil) { levels = depth_by_walk(s); }   // longer than the wave covers
+        return make_chain(mine, levels, lane);
+    }
+    __device__ __forceinline__ Chain make_chain(int mine, int levels, int lane) const {
         Chain c;
         c.mine = mine;
         c.par = lane_above(mine);            // lane k+1 holds the parent
@@ -532,8 +533,8 @@ struct Tree {
     }
 
     // ---------------- restructuring, whole wave -------------------------------------------------
-    // sibling order under i's parent (huffman.h:64-86)
-    __device__ __forceinline__ void order_only(int i, int lane) {
+    // sibling order under i's parent (huffman.h:64-86); dp = that parent's depth
+    __device__ __forceinline__ void order_only(int i, uint32_t dp, int lane) {
         const uint32_t p = up_of(i);
         if (p == kNil) { return; }
         const uint32_t w = lds->lnk[p];
@@ -542,54 +543,76 @@ struct Tree {
         if (swap) {
             if (lane == 0) { lds->lnk[p] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
             lds_fence();
-            swap_fix((int)p, lane);
+            swap_fix((int)p, dp, lane);
         }
     }
 
-    // the climb of huffman_frequency_changed from node i (huffman.h:132-142): lane k owns level
-    // k of i's root path; new sums by prefix sum, sibling order per level, one pending pair per
-    // level (bottom first)
-    __device__ __forceinline__ int climb_wave(int i, int sp, int lane) {
-        const Chain c = chain_up(i, lane);
+    // The climb of huffman_frequency_changed (huffman.h:132-142) along the chain `c` from its level
+    // k0 upwards: lane k >= k0 owns the edge from level k to its parent; new sums by prefix sum,
+    // sibling order per level, the parents' first / last leaves, one pending pair per level (bottom
+    // first, appended at pend[sp]).
+    __device__ __forceinline__ int climb_wave(const Chain& c, int k0, int sp, int lane) {
         const int levels = c.levels;
-        if (levels >= kMaxFastDepth || sp + levels > kWave) { fault = 1; return 0; }
-        if (levels == 0) {                                            // i is the root
-            if (lane == 0) { sum(i); }
+        const int span = levels - k0;
+        if (levels >= kMaxFastDepth || sp + span > kWave) { fault = 1; return 0; }
+        const int start = __builtin_amdgcn_readlane(c.mine, k0);
+        if (span <= 0) {                                              // the start node is the root
+            if (lane == 0) { sum(start); }
             lds_fence();
             return sp;
         }
-        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)freq(i));
-        const int x = c.active ? c.mine : kRoot;
-        const int p = c.active ? c.par : kRoot;
+        const bool act = lane >= k0 && lane < levels;
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)freq(start));
+        const int x = act ? c.mine : kRoot;
+        const int p = act ? c.par : kRoot;
         const uint32_t pw = lds->lnk[p];
         const bool is_hi = l_hi(pw) == (uint32_t)x;
         const uint32_t sib = is_hi ? l_lo(pw) : l_hi(pw);
-        const bool has_sib = c.active & (sib != kNil);
+        const bool has_sib = act & (sib != kNil);
         const uint32_t fs = has_sib ? freq((int)sib) : 0u;
-        const uint32_t incl = wave_scan(c.active ? fs : 0u);
+        const uint32_t incl = wave_scan(act ? fs : 0u);
         const uint32_t fx = f0 + incl - fs;                          // my node's count, refreshed
         const bool swap = has_sib & (is_hi ? (fs > fx) : (fx > fs));  // lo count > hi count
-#ifdef SQZ_DEBUG_TREE
-        if (g_dbg_on && lane < 6) { printf("climb i=%d lane=%d x=%d p=%d sib=%u fs=%u fx=%u swap=%d active=%d\n", i, lane, x, p, sib, fs, fx, (int)swap, (int)c.active); }
-#endif
-        if (c.active) {
-            // the parent sits levels - lane - 1 below the root
-            lds->cnt[p] = aux != 0 ? (((f0 + incl) & kCountMask) | ((uint32_t)(levels - lane - 1) << kDepthShift)) : (f0 + incl);
+        // first / last leaf of every parent on the chain: the first leaf of level k+1 is the sibling's
+        // where x ends up as the hi child, else what came up from below; the last leaf the other way round
+        uint32_t ends = 0;
+        if (aux != 0) {
+            const bool ends_hi = act & (is_hi != swap);
+            const uint32_t sw = has_sib ? lds->rng[sib] : 0u;
+            const uint32_t sF = has_sib ? (is_leaf(sib) ? sib : r_first(sw)) : (uint32_t)x;
+            const uint32_t sL = has_sib ? (is_leaf(sib) ? sib : r_last(sw)) : (uint32_t)x;
+            const uint32_t F0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_leaf((uint32_t)start));
+            const uint32_t L0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)last_leaf((uint32_t)start));
+            const uint64_t below = (2ull << lane) - 1ull;             // lanes <= mine
+            // (a node without a sibling -- the root's only child -- passes both ends up unchanged)
+            const uint64_t mh = __ballot(ends_hi & has_sib) & below, ml = __ballot(act & !ends_hi & has_sib) & below;
+            const uint32_t fF = (uint32_t)__builtin_amdgcn_ds_bpermute(mh != 0 ? (63 - __builtin_clzll(mh)) * 4 : 0, (int)sF);
+            const uint32_t fL = (uint32_t)__builtin_amdgcn_ds_bpermute(ml != 0 ? (63 - __builtin_clzll(ml)) * 4 : 0, (int)sL);
+            ends = (mh != 0 ? fF : F0) | ((ml != 0 ? fL : L0) << 10);
+        }
+        if (act) {
+            lds->cnt[p] = aux != 0 ? ((f0 + incl) & kCountMask) : (f0 + incl);
             if (swap) { lds->lnk[p] = mk_lnk(l_up(pw), l_hi(pw), l_lo(pw)); }
-            lds->pend[sp + lane] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
+            if (aux != 0) { lds->rng[p] = (lds->rng[p] & ~kEndsMask) | ends; }
+            lds->pend[sp + lane - k0] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
         }
         lds_fence();
         uint64_t swaps = __ballot(swap);
         while (swaps != 0) {                                          // rare: one pass per exchanged pair
             const int k = __builtin_ctzll(swaps);
             swaps &= swaps - 1;
-            swap_fix(__builtin_amdgcn_readlane(p, k), lane);
+            swap_fix(__builtin_amdgcn_readlane(p, k), (uint32_t)(levels - k - 1), lane);
         }
-        return sp + levels;
+        return sp + span;
     }
 
-    __device__ __forceinline__ void changed_all(int start, int lane) {
-        int sp = climb_wave(start, 0, lane);
+    // huffman_frequency_changed + move_up along the chain `c` of the node whose count changed.  The
+    // chain stays valid throughout: a promotion under g changes nothing above g, and the climb that
+    // follows it starts at g.
+    __device__ __forceinline__ void changed_all(const Chain& c_in, int lane) {
+        Chain c = c_in;
+        int valid_from = 0;                                           // lanes of `c` from here up are a true root path
+        int sp = climb_wave(c, 0, 0, lane);
         // (a promotion moves a node up, so a symbol's update makes fewer of them than the tree is
         // deep; the bound only keeps a wave from spinning on a corrupted tree: it faults instead)
         for (int guard = 0; sp > 0; guard++) {
@@ -611,10 +634,6 @@ struct Tree {
                 }
             }
             const uint64_t hits = __ballot(hit);
-#ifdef SQZ_DEBUG_TREE
-            if (g_dbg_on && lane == 0) { printf("changed_all sp=%d hits=%llx guard=%d\n", sp, (unsigned long long)hits, guard); }
-            if (g_dbg_on && lane < sp && lane < 8) { printf("  pend lane=%d p=%d ch=%d g=%d uncle=%d hit=%d\n", lane, p, ch, g, uncle, (int)hit); }
-#endif
             if (hits == 0) { break; }
             const int j = 63 - __builtin_clzll(hits);
             sp = j;
@@ -623,6 +642,15 @@ struct Tree {
             g = __builtin_amdgcn_readlane(g, j);
             uncle = __builtin_amdgcn_readlane(uncle, j);
             left = __builtin_amdgcn_readlane(left, j);
+            // g's level on the chain (the lane holding it) gives its depth and where the next climb
+            // starts.  A promotion leaves the chain ABOVE its g intact; a later hit further down (an
+            // older pending pair) finds its g off the intact part: take g's root path afresh then.
+            const uint64_t at_g = __ballot(c.holds && c.mine == g && lane >= valid_from);
+            int kg = 0;
+            if (at_g != 0) { kg = __builtin_ctzll(at_g); }
+            else { c = chain_up(g, lane); }
+            valid_from = kg;
+            const uint32_t dg = (uint32_t)(c.levels - kg);
             if (lane == 0) {                                          // move_up, :110-119
                 lds->lnk[ch] = (lds->lnk[ch] & ~0x3FFu) | (uint32_t)g;
                 const uint32_t gw = lds->lnk[g];
@@ -632,19 +660,23 @@ struct Tree {
                 lds->lnk[uncle] = (lds->lnk[uncle] & ~0x3FFu) | (uint32_t)p;
             }
             lds_fence();
-            if (aux != 0) {
-                promote_fix(g, p, ch, uncle, left, lane);
-            } else {                                                  // depths by a walk (deep tree)
-                stats.moves += 1;
-            }
+            promote_fix(g, dg, p, ch, uncle, left, lane);
             if (lane == 0) { sum(p); sum(g); }                        // :120-121
             lds_fence();
-            order_only(ch, lane);                                     // :122-124
-            order_only(uncle, lane);
-            order_only(p, lane);
-            if (aux != 0) { mark_subtree(g, lane); }                  // :125 huffman_update_paths(gix)
+            order_only(ch, dg, lane);                                 // :122-124 (ch hangs under g now)
+            order_only(uncle, dg + 1u, lane);                         //          (the uncle under p)
+            order_only(p, dg, lane);
+            if (aux != 0) {
+                // an exchange under p moved p's ends: g's follow (everything above g is redone by the climb)
+                if (lane == 0) {
+                    const uint32_t gw = lds->lnk[g];
+                    set_ends(g, first_leaf(l_lo(gw)), last_leaf(l_hi(gw)));
+                }
+                lds_fence();
+                mark_subtree(g, lane);                                // :125 huffman_update_paths(gix)
+            }
             else { if (lane == 0) { relabel(g); } uniform_regs(); lds_fence(); }
-            sp = climb_wave(g, sp, lane);                             // :126
+            sp = climb_wave(c, kg, sp, lane);                         // :126
         }
     }
 
@@ -677,7 +709,7 @@ struct Tree {
             if (c.holds) { lds->cnt[c.mine] = cw + 1; }
             lds_fence();
         } else {
-            changed_wave(s, lane);
+            changed_wave(s, c, lane);
         }
         return code_bits;
     }
@@ -705,11 +737,11 @@ struct Tree {
         return (r >> 31) != 0;
     }
 
-    __device__ __forceinline__ void changed_wave(int s, int lane) {
+    __device__ __forceinline__ void changed_wave(int s, const Chain& c, int lane) {
         SQZ_ST_BEGIN
         const TreeStats keep = stats;
         unpack_regs((uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)slow_changed<Tree>(lds, code, pack_regs(), s, lane)));
+            (int)slow_changed<Tree>(lds, code, pack_regs(), s, c.mine, c.levels, lane)));
         stats = keep;
         load_stats_delta();
         lut_ok = 0;
@@ -736,8 +768,8 @@ struct Tree {
     }
 
     // ---------------- huffman_insert (huffman.h:149-216), whole wave -------------------------------
-    // lane 0 hangs the leaf into the links; positions, codes and partners follow by flat passes; then
-    // the climb and the promotions like any other update, and the closing walk of :213.
+    // lane 0 hangs the leaf into the links; positions, codes and partners follow; then the climb and
+    // the promotions like any other update, and the closing walk of :213.
     __device__ __forceinline__ bool insert_all(int i, int lane) {
         uint32_t hand = 0;       // start | at << 10 | ok << 20 | split << 21 ; q in the high bits
         if (lane == 0) {
@@ -756,22 +788,21 @@ struct Tree {
                 lds->lnk[at] = to_hi ? mk_lnk(l_up(aw), l_lo(aw), (uint32_t)leaf) : mk_lnk(l_up(aw), (uint32_t)leaf, l_hi(aw));
                 lds->lnk[leaf] = mk_lnk((uint32_t)at, kNil, kNil);
                 set_freq(at, freq(at) + 1u);
-                // the tree is tiny (at IS the root: a split always makes two children): rebuild its aux by hand
-                const uint32_t w2 = lds->lnk[at];
-                const uint32_t lo = aux != 0 ? l_lo(w2) : kNil, hi = aux != 0 ? l_hi(w2) : kNil;
-                if (aux != 0) { set_depth(leaf, c_d(lds->cnt[at]) + 1u); }
-                uint32_t pos = (uint32_t)POS0;
-                if (lo != kNil) {
-                    lds->rng[lo] = mk_rng(pos, pos + 1, hi);           // a lo child is tested against its sibling
-                    if (CODES) { code[code_slot((int)lo)] = 0u; }
-                    pos++;
-                }
-                if (hi != kNil) {
-                    lds->rng[hi] = mk_rng(pos, pos + 1, kNil);         // a hi child of the root has no test
+                if (aux != 0) {
+                    // the tree is tiny (at IS the root: a split always makes two children): its positions by hand
+                    lds->cnt[leaf] = 1u | (1u << kDepthShift);
+                    const uint32_t w2 = lds->lnk[at];
+                    const uint32_t lo = l_lo(w2), hi = l_hi(w2);
+                    uint32_t pos = (uint32_t)POS0;
+                    if (lo != kNil) {
+                        lds->rng[lo] = pos | (hi << 20);               // a lo child is tested against its sibling
+                        if (CODES) { code[code_slot((int)lo)] = 0u; }
+                        pos++;
+                    }
+                    lds->rng[hi] = pos | (kNil << 20);                 // a hi child of the root has no test
                     if (CODES) { code[code_slot((int)hi)] = 1u; }
-                    pos++;
+                    lds->rng[at] = (lo != kNil ? lo : hi) | (hi << 10) | (kNil << 20);
                 }
-                if (aux != 0) { lds->rng[at] = mk_rng((uint32_t)POS0, pos, kNil); }
             } else if (next >= kIdEnd) {                               // :180-182
                 ok = 0;
                 complete = 1;
@@ -780,9 +811,9 @@ struct Tree {
                 const int fresh = next++;
                 const uint32_t above = l_up(lds->lnk[at]);
                 const uint32_t acw = lds->cnt[at];
-                q = r_st(lds->rng[at]);
+                q = r_pos(lds->rng[at]);
                 lds->lnk[fresh] = mk_lnk(above, (uint32_t)at, (uint32_t)leaf);
-                lds->cnt[fresh] = acw;                                 // at's count and depth
+                lds->cnt[fresh] = aux != 0 ? c_f(acw) : acw;           // at's count
                 const uint32_t bw = lds->lnk[above];
                 lds->lnk[above] = l_lo(bw) == (uint32_t)at ? mk_lnk(l_up(bw), (uint32_t)fresh, l_hi(bw))
                                                            : mk_lnk(l_up(bw), l_lo(bw), (uint32_t)fresh);
@@ -791,6 +822,7 @@ struct Tree {
                 if (aux != 0) {                                        // both children one level below at's old place
                     lds->cnt[at] = acw + (1u << kDepthShift);
                     lds->cnt[leaf] = 1u | ((c_d(acw) + 1u) << kDepthShift);
+                    lds->rng[fresh] = (uint32_t)at | ((uint32_t)leaf << 10) | (kNil << 20);
                 }
                 sum(fresh);
                 at = fresh;
@@ -805,22 +837,19 @@ struct Tree {
         const bool ok = ((hand >> 20) & 1u) != 0, split = ((hand >> 21) & 1u) != 0;
         const uint32_t q = hand >> 22;
         if (split && aux != 0) {
-            // every position behind q moves one to the right, then the three nodes of the split
+            // every leaf behind position q moves one to the right; the new leaf takes q + 1
             const int fresh = at;
-            for (int v = BASE + lane; v < next; v += kWave) {
-                const uint32_t w = lds->rng[v];
-                const uint32_t s = r_st(w), e = r_en(w);
-                if (e > s && v != fresh && v != i) {
-                    const uint32_t ns = s > q ? s + 1 : s, ne = e > q ? e + 1 : e;
-                    if (ne != e) { lds->rng[v] = (w & ~0x3FFFFu) | ns | (ne << 9); }
-                }
+            const uint32_t leaf_at = l_lo(lds->lnk[fresh]);
+#pragma unroll
+            for (int r = 0; r < kLeafRows; r++) {
+                const int v = BASE + r * kWave + lane;
+                if (BASE + r * kWave >= kRoot) { break; }
+                const int vv = v < kRoot ? v : kRoot;
+                const uint32_t w = lds->rng[vv];
+                if (v < kRoot && v != i && c_d(lds->cnt[vv]) != 0 && r_pos(w) > q) { lds->rng[v] = w + 1u; }
             }
-            lds_fence();
             if (lane == 0) {
-                const uint32_t leaf_at = l_lo(lds->lnk[fresh]);
-                lds->rng[fresh] = mk_rng(q, q + 2, kNil);
-                lds->rng[leaf_at] = mk_rng(q, q + 1, kNil);            // (its end was moved by the pass: set it again)
-                lds->rng[i] = mk_rng(q + 1, q + 2, kNil);
+                lds->rng[i] = (q + 1u) | (kNil << 20);
                 if (CODES) {
                     const uint32_t oc = code[code_slot((int)leaf_at)];
                     code[code_slot((int)leaf_at)] = oc << 1;
@@ -830,6 +859,7 @@ struct Tree {
             lds_fence();
             fix_partners((int)l_up(lds->lnk[fresh]), 2, lane);         // fresh, its sibling, and their children
         }
+        uint32_t droot = 0;
         if (!split && ok) {                                            // :173 order under the root
             const uint32_t w = lds->lnk[at];
             if (__builtin_amdgcn_readfirstlane(
@@ -837,7 +867,7 @@ struct Tree {
                 if (lane == 0) { lds->lnk[at] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
                 lds_fence();
                 start = start == (int)l_lo(w) ? (int)l_hi(w) : (int)l_lo(w);
-                swap_fix(at, lane);
+                swap_fix(at, droot, lane);
             }
         }
         if (depth + 4 >= kMaxFastDepth) {                              // chains longer than the wave: the reference sequence on one lane
@@ -846,7 +876,8 @@ struct Tree {
             uniform_regs();
             lds_fence();
         } else {
-            changed_all(start, lane);                                  // :212
+            const Chain c = chain_up(start, lane);
+            changed_all(c, lane);                                      // :212
             if (aux != 0) { mark_subtree(at, lane); }                  // :213
             else { if (lane == 0) { relabel(at); } uniform_regs(); lds_fence(); }
         }
@@ -866,23 +897,20 @@ __device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint3
 }
 
 template <class T>
-__device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane) {
+__device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane) {
     T t;
     t.lds = lds; t.code = code; t.lut = nullptr; t.lut_ok = 0;
     t.stats.updates = t.stats.swaps = t.stats.moves = 0;
     t.unpack_regs(regs);
     if (lane == 0) { t.lds->cnt[sym] += 1u; }
     lds_fence();
-#ifdef SQZ_DEBUG_TREE
-    if (g_dbg_on && lane == 0) { printf("slow_changed sym=%d aux=%d depth=%d next=%d\n", sym, t.aux, t.depth, t.next); }
-#endif
     if (t.depth + 4 >= kMaxFastDepth) {                 // chains longer than the wave: one lane, explicit stacks
         t.give_up_aux(lane);
         if (lane == 0) { t.changed(sym); }
         t.uniform_regs();
         lds_fence();
     } else {
-        t.changed_all(sym, lane);
+        t.changed_all(t.make_chain(mine, levels, lane), lane);      // the chain bump_wave already holds
     }
     t.store_stats_delta(lane);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pack_regs());
@@ -944,18 +972,19 @@ template <bool CODES> using PosTreeT = Tree<kPosBase, kPosLeaves, kPosNodes, 32,
 //
 // Returns how many leading tokens were applied (0..m).  code_a/depth_a/code_b/depth_b are the
 // static tree's and valid for all m lanes (kWantCode: the encoder emits them, the decoder has no
-// use for them).  Only callable while both trees keep their intervals (aux) and take updates.
+// use for them).  Only callable while both trees keep their positions (aux) and take updates.
 template <bool kWantCode, class LIT, class POS>
 __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, const LIT& lit, const POS& pos,
                                           int lane, int m, int a, int b,
                                           uint32_t& code_a, int& depth_a, uint32_t& code_b, int& depth_b) {
     const bool take = lane < m;
     const bool has_a = take && a >= 0, has_b = take && b >= 0;
-    const int ia = has_a ? a : LIT::kRoot, ib = has_b ? b : POS::kRoot;
+    const int ia = has_a ? a : LIT::kRoot - 1, ib = has_b ? b : POS::kRoot - 1;      // (idle lanes look at a pad leaf)
     const uint32_t ra = lds->rng[ia], rb = lds->rng[ib];
-    const uint32_t qa = r_st(ra), qb = r_st(rb);
-    depth_a = (int)c_d(lds->cnt[ia]);
-    depth_b = (int)c_d(lds->cnt[ib]);
+    const uint32_t qa = r_pos(ra), qb = r_pos(rb);
+    const uint32_t wa = lds->cnt[ia], wb = lds->cnt[ib];
+    depth_a = (int)c_d(wa);
+    depth_b = (int)c_d(wb);
     if (kWantCode) {
         code_a = code[has_a ? ia - LIT::kBase + 0 : 0];
         code_b = code[has_b ? ib - POS::kBase + kPosPos0 : 0];
@@ -976,76 +1005,100 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         lds->P64[lane] = (incl << 8) + (uint64_t)base * 0x0101010101010101ull;     // exclusive: P[i] = symbols at positions < i
         lds_fence();
     };
-    histogram(m);
-    // ---- every touched node's test ---------------------------------------------------------------
-    int ok = m;
-    auto test = [&](int v, bool on, uint32_t& n_out) {
+    // how many of the batch's chains pass node v, and the node's test: f + n <= count of its partner
+    struct Probe { uint32_t st, en, n, f, fb; bool tested; };
+    auto probe = [&](int v, bool leaf, bool on) {
+        Probe r;
         const uint32_t w = lds->rng[v];
-        const uint32_t n = on ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
-        n_out = n;
-        const uint32_t pa = r_pa(w);
-        const bool tested = n != 0 && pa != kNil;
-        const uint32_t f = c_f(lds->cnt[v]);
-        const uint32_t fb = c_f(lds->cnt[tested ? pa : (uint32_t)v]);
-        const bool viol = tested && f + n > fb;
-        uint64_t vm = __ballot(viol);
-        while (vm != 0) {                                   // rare: find the token that may not pass
-            const int k = __builtin_ctzll(vm);
-            vm &= vm - 1;
-            const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)w, k);
-            const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)f, k);
-            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)fb, k);
-            const uint32_t allowed = bk > fk ? bk - fk : 0u;     // tokens through the node that may pass
-            const uint32_t s = r_st(wk), e = r_en(wk);
-            const bool through = (has_a && qa >= s && qa < e) || (has_b && qb >= s && qb < e);
-            const uint64_t tm = __ballot(through);
-            const uint64_t first_bad = __ballot(through && lanes_under(tm) == allowed);
-            if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
+        if (leaf) {
+            r.st = r_pos(w); r.en = r.st + 1u;
+        } else {
+            r.st = r_pos(lds->rng[r_first(w)]);
+            r.en = r_pos(lds->rng[r_last(w)]) + 1u;
         }
+        r.n = on ? (uint32_t)lds->P8[r.en] - (uint32_t)lds->P8[r.st] : 0u;
+        const uint32_t pa = r_pa(w);
+        r.tested = r.n != 0 && pa != kNil;
+        r.f = c_f(lds->cnt[v]);
+        r.fb = c_f(lds->cnt[r.tested ? pa : (uint32_t)v]);
+        return r;
     };
-    // the tokens' own leaves (duplicates test the same node twice: harmless), then the internal nodes
-    uint32_t na, nb;
-#ifdef SQZ_DEBUG_TREE
-    if (g_dbg_on && lane < 2) { printf("batch lane=%d m=%d a=%d b=%d qa=%u P64=%llx P8[qa]=%u P8[qa+1]=%u rng=%x cnt=%x\n", lane, m, a, b, qa, (unsigned long long)lds->P64[lane], (unsigned)lds->P8[qa], (unsigned)lds->P8[qa + 1], ra, lds->cnt[ia]); }
-#endif
-    test(ia, has_a, na);
-#ifdef SQZ_DEBUG_TREE
-    if (g_dbg_on && lane < 1) { printf("batch after leaf test: na=%u ok=%d\n", na, ok); }
-#endif
-    test(ib, has_b, nb);
+    histogram(m);
+    // ---- every touched node's test: the tokens' own leaves (duplicates test the same node twice:
+    //      harmless), then the internal nodes, one lane per node ------------------------------------
     constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
-    uint32_t nl[kLitRows], np;
+    uint32_t nl[kLitRows], np = 0;
+    uint32_t bad = 0;                                   // bit 0 / 1: my leaves; bit 2 + r: my node of lit row r; bit 7: pos row
+    {
+        const Probe r = probe(ia, true, has_a);
+        bad |= (r.tested && r.f + r.n > r.fb) ? 1u : 0u;
+    }
+    {
+        const Probe r = probe(ib, true, has_b);
+        bad |= (r.tested && r.f + r.n > r.fb) ? 2u : 0u;
+    }
 #pragma unroll
-    for (int r = 0; r < kLitRows; r++) {
-        const int v = LIT::kRoot + r * kWave + lane;
-        if (LIT::kRoot + r * kWave < lit.next) { test(v < lit.next ? v : LIT::kRoot, v < lit.next && v != LIT::kRoot, nl[r]); }
-        else { nl[r] = 0; }
+    for (int row = 0; row < kLitRows; row++) {
+        const int v = LIT::kRoot + row * kWave + lane;
+        nl[row] = 0;
+        if (LIT::kRoot + row * kWave < lit.next) {
+            const bool on = v < lit.next && v != LIT::kRoot;
+            const Probe r = probe(on ? v : LIT::kRoot, false, on);
+            nl[row] = r.n;
+            bad |= (r.tested && r.f + r.n > r.fb) ? (4u << row) : 0u;
+        }
     }
     {
         const int v = POS::kRoot + lane;
-        test(v < pos.next ? v : POS::kRoot, v < pos.next && v != POS::kRoot, np);
+        const bool on = v < pos.next && v != POS::kRoot;
+        const Probe r = probe(on ? v : POS::kRoot, false, on);
+        np = r.n;
+        bad |= (r.tested && r.f + r.n > r.fb) ? 128u : 0u;
     }
-    // ---- apply the prefix ----------------------------------------------------------------------------
-    if (ok < m) {                                               // cut short: count again for the prefix only
+    int ok = m;
+    if (__ballot(bad != 0) != 0) {
+        // rare: some node would overtake its partner.  For each such node, the token that may not
+        // pass is the (partner's count - its count + 1)-th one whose position lies below the node;
+        // the earliest of them over all failing nodes ends the batch.
+#pragma unroll
+        for (int cat = 0; cat < 8; cat++) {
+            uint64_t vm = __ballot((bad >> cat) & 1u);
+            while (vm != 0) {
+                const int k = __builtin_ctzll(vm);
+                vm &= vm - 1;
+                int v;
+                if (cat == 0) { v = __builtin_amdgcn_readlane(ia, k); }
+                else if (cat == 1) { v = __builtin_amdgcn_readlane(ib, k); }
+                else if (cat == 7) { v = POS::kRoot + k; }
+                else { v = LIT::kRoot + (cat - 2) * kWave + k; }
+                const Probe r = probe(v, cat < 2, true);       // uniform: every lane looks at node v
+                const uint32_t allowed = r.fb > r.f ? r.fb - r.f : 0u;     // tokens through the node that may pass
+                const bool through = (has_a && qa >= r.st && qa < r.en) || (has_b && qb >= r.st && qb < r.en);
+                const uint64_t tm = __ballot(through);
+                const uint64_t first_bad = __ballot(through && lanes_under(tm) == allowed);
+                if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
+            }
+        }
+        // count again for the prefix only
         histogram(ok);
 #pragma unroll
-        for (int r = 0; r < kLitRows; r++) {
-            const int v = LIT::kRoot + r * kWave + lane;
-            const uint32_t w = lds->rng[v < lit.next ? v : LIT::kRoot];
-            nl[r] = (v < lit.next && v != LIT::kRoot) ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
+        for (int row = 0; row < kLitRows; row++) {
+            const int v = LIT::kRoot + row * kWave + lane;
+            const bool on = v < lit.next && v != LIT::kRoot;
+            nl[row] = probe(on ? v : LIT::kRoot, false, on).n;
         }
         const int v = POS::kRoot + lane;
-        const uint32_t w = lds->rng[v < pos.next ? v : POS::kRoot];
-        np = (v < pos.next && v != POS::kRoot) ? (uint32_t)lds->P8[r_en(w)] - (uint32_t)lds->P8[r_st(w)] : 0u;
+        const bool on = v < pos.next && v != POS::kRoot;
+        np = probe(on ? v : POS::kRoot, false, on).n;
     }
-    // leaves: one add per token (lanes holding the same symbol meet at its leaf); internal nodes:
-    // one add per node, by the lane that tested it
+    // ---- apply the prefix: leaves one add per token (lanes holding the same symbol meet at its
+    //      leaf); internal nodes one add per node, by the lane that tested it --------------------------
     if (lane < ok && has_a) { atomicAdd(&lds->cnt[ia], 1u); }
     if (lane < ok && has_b) { atomicAdd(&lds->cnt[ib], 1u); }
 #pragma unroll
-    for (int r = 0; r < kLitRows; r++) {
-        const int v = LIT::kRoot + r * kWave + lane;
-        if (nl[r] != 0) { lds->cnt[v] += nl[r]; }
+    for (int row = 0; row < kLitRows; row++) {
+        const int v = LIT::kRoot + row * kWave + lane;
+        if (nl[row] != 0) { lds->cnt[v] += nl[row]; }
     }
     if (np != 0) { lds->cnt[POS::kRoot + lane] += np; }
     lds_fence();

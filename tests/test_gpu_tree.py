@@ -78,20 +78,23 @@ def compare(which, head, nodes, n_ref, ref, ref_info, counters=None):
     if counters is not None:
         assert [int(head[5]), int(head[6]), int(head[7])] == [int(c) for c in counters]
     lnk = lambda v: (int(nodes[v - base][0]) & NIL, (int(nodes[v - base][0]) >> 10) & NIL, (int(nodes[v - base][0]) >> 20) & NIL)
-    rng = lambda v: (int(nodes[v - base][1]) & 0x1FF, (int(nodes[v - base][1]) >> 9) & 0x1FF, (int(nodes[v - base][1]) >> 18) & NIL)
+    # rng word: a leaf's position (low 9 bits), an internal node's first | last << 10 leaf; partner << 20
+    rng = lambda v: int(nodes[v - base][1])
     cnt = lambda v: (int(nodes[v - base][2]) & 0xFFFFFF, (int(nodes[v - base][2]) >> 24) & 0x3F)
-    stack, pos = [(root_d, root_r)], pos0
+    stack, pos = [(root_d, root_r, 0)], pos0
     seen = 0
+    ends = {}                                                  # node -> (leftmost leaf, rightmost leaf) by the walk
+    order = []
     while stack:
-        v, w = stack.pop()
+        v, w, depth = stack.pop()
         up, lo, hi = lnk(v)
-        st, en, pa = rng(v)
         f, d = cnt(v)
+        pa = (rng(v) >> 20) & NIL
         seen += 1
+        order.append(v)
         if v != root_d:
             assert f == int(freq[w]), ("freq", v, w)
-        assert d == int(bits[w]), ("depth", v, w)
-        assert st == pos, ("interval start", v)
+        assert depth == int(bits[w]), ("depth", v, w)
         # the cached test partner: sibling for a lo child, uncle for a hi child below the root's children
         if v != root_d:
             pu, plo, phi = lnk(up)
@@ -102,30 +105,32 @@ def compare(which, head, nodes, n_ref, ref, ref_info, counters=None):
                 g = lnk(pu)
                 want = g[2] if g[1] == up else g[1]
             assert pa == want, ("partner", v, pa, want)
-        if v < root_d:                                        # a leaf: same symbol, same code
+        if v < root_d:                                        # a leaf: same symbol, same code, its place in leaf order
             assert v - base == w, ("leaf id", v, w)
             assert lo == NIL and hi == NIL and int(lix[w]) == -1 and int(rix[w]) == -1
+            assert d == depth, ("stored leaf depth", v, d, depth)
             assert int(nodes[v - base][3]) == rev_bits(path[w], int(bits[w])), ("code", v)
-            assert en == pos + 1
+            assert rng(v) & 0x1FF == pos, ("leaf position", v, rng(v) & 0x1FF, pos)
+            ends[v] = (v, v)
             pos += 1
             continue
         assert (lo == NIL) == (int(lix[w]) == -1) and (hi == NIL) == (int(rix[w]) == -1), ("children", v, w)
         if hi != NIL:
             assert lnk(hi)[0] == v
-            stack.append((hi, int(rix[w])))
+            stack.append((hi, int(rix[w]), depth + 1))
         if lo != NIL:
             assert lnk(lo)[0] == v
-            stack.append((lo, int(lix[w])))
-    # every interval closes where its last leaf ends
-    for v in range(root_d, int(head[0])):
-        up, lo, hi = lnk(v)
-        if v != root_d and up == NIL:
+            stack.append((lo, int(lix[w]), depth + 1))
+    # every internal node names its leftmost and rightmost leaf
+    for v in reversed(order):
+        if v < root_d:
             continue
-        st, en, _ = rng(v)
-        last = hi if hi != NIL else lo
-        first = lo if lo != NIL else hi
-        if first != NIL:
-            assert st == rng(first)[0] and en == rng(last)[1], ("interval", v)
+        up, lo, hi = lnk(v)
+        kids = [k for k in (lo, hi) if k != NIL]
+        if not kids:
+            continue
+        ends[v] = (ends[kids[0]][0], ends[kids[-1]][1])
+        assert (rng(v) & NIL, (rng(v) >> 10) & NIL) == ends[v], ("ends", v, rng(v) & NIL, (rng(v) >> 10) & NIL, ends[v])
     attached = sum(1 for i in range(2 * n_ref - 1) if i == root_r or int(pix[i]) != -1)
     assert seen == attached
 
