@@ -41,8 +41,8 @@ struct DecodeLds {
     uint32_t   stage[kStageDw];
 };
 
-using LitTree = LitTreeT<false>;
-using PosTree = PosTreeT<false>;
+using LitTree = LitTreeT<false, false>;
+using PosTree = PosTreeT<false, false>;
 
 // squeeze.h:429-442; returns the leaf or -1 with err set.  The first 8 levels
 // of the root->leaf walk come from the lookup table (rebuilt whenever the tree
@@ -96,7 +96,7 @@ __device__ __forceinline__ int peek_symbol(BitSource& r, const T& t) {
 // escape, a restructuring update, malformed input) is decoded again by the
 // one-at-a-time path from its own bit position, so errors and updates are the
 // reference's.
-__global__ __launch_bounds__(kWave)
+__global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
 void entropy_decode_kernel(const uint8_t* __restrict__ in,
                            const uint64_t* __restrict__ in_off,
                            const uint64_t* __restrict__ out_off,
@@ -437,7 +437,7 @@ __device__ __forceinline__ uint8_t load_l2(const uint8_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kWave)
+__global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
 void lz_expand_kernel(const uint32_t* __restrict__ tokens,
                          const uint32_t* __restrict__ tok_count,
                          uint8_t* __restrict__ out,

@@ -18,6 +18,7 @@
 // chain, code = one __ballot("am I the hi child?"), the reference's own swap / promote tests,
 // restructuring on the whole wave; its bits wait in a register and ride along with the next
 // batch's pack.
+#define SQZ_SEC_TIMERS            // (stats build: the section timers of sqz_tree.h report through this kernel)
 #include "sqz_tree.h"
 #include "sqz_kernels.h"
 
@@ -30,8 +31,6 @@ struct EmitLds {
     uint32_t code[kCodeSlots];
 };
 
-using LitTree = LitTreeT<true>;
-using PosTree = PosTreeT<true>;
 
 struct BitQueue {
     EmitLds* lds;
@@ -178,6 +177,7 @@ __device__ __forceinline__ void emit_coded(BitQueue& q, T& t, int s, int nyt, in
 }
 
 // one token word -> its bit fields (squeeze.h:377-394 -> :278-315), one symbol at a time
+template <class LitTree, class PosTree>
 __device__ __forceinline__ void emit_token(BitQueue& q, LitTree& lit, PosTree& pos, uint32_t t,
                                            int lane, int& err) {
     const bool is_match = (t & kTokMatch) != 0;
@@ -211,7 +211,8 @@ __device__ __forceinline__ bool token_ok(uint32_t t) {
 // bump_batch); a step shrinks to the tokens in front of the first unseen or malformed one, then to
 // the longest prefix that changes no link, and the token it stops at (the tree really
 // restructures, or it needs the NYT escape) goes through the one-at-a-time path in the same step.
-__global__ __launch_bounds__(kWave)
+template <bool kStats>                         // kStats: keep the reference's counters (sqz_block_stats)
+__global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
 void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                          const uint64_t* __restrict__ tok_off,
                          const uint32_t* __restrict__ tok_count,
@@ -227,6 +228,8 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
 
+    using LitTree = LitTreeT<true, kStats>;
+    using PosTree = PosTreeT<true, kStats>;
     LitTree lit; PosTree pos;
     lit.lds = &lds.tree; lit.code = lds.code; lit.lut = nullptr;
     pos.lds = &lds.tree; pos.code = lds.code; pos.lut = nullptr;
@@ -334,10 +337,11 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             }
             if (lane >= m) { n1 = 0; n2 = 0; }
             q.pack_lanes(v1, n1, v2, n2, lane);                        // what the last one-at-a-time token left goes first
-            // squeeze.h:386,391: source bytes coded as back references / as literals
-            const uint64_t mm = __ballot(lane < m && is_match);
-            lit_tokens += (uint32_t)(m - __builtin_popcountll(mm));
-            match_bytes += wave_sum((lane < m && is_match) ? tlen : 0u);
+            if (kStats) {                                              // squeeze.h:386,391: source bytes coded as back references / as literals
+                const uint64_t mm = __ballot(lane < m && is_match);
+                lit_tokens += (uint32_t)(m - __builtin_popcountll(mm));
+                match_bytes += wave_sum((lane < m && is_match) ? tlen : 0u);
+            }
             cursor += (uint32_t)m;
         }
         ES(2)
@@ -347,7 +351,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)traw, m);
             if (!token_ok(tx)) { err = kEINVAL; break; }
             emit_token(q, lit, pos, tx, lane, err);
-            if ((tx & kTokMatch) != 0) { match_bytes += (tx >> 16) & 0x1FFu; } else { lit_tokens += 1; }
+            if (kStats) { if ((tx & kTokMatch) != 0) { match_bytes += (tx >> 16) & 0x1FFu; } else { lit_tokens += 1; } }
             cursor += 1;
 #ifdef SQZ_STATS
             es_exact++;
@@ -375,6 +379,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         printf("emit block 1: cycles %llu steps %u exact %u: prep %llu bump %llu pack %llu exact %llu\n",
                (unsigned long long)(es_last - es_begin), es_steps, es_exact, (unsigned long long)es[0],
                (unsigned long long)es[1], (unsigned long long)es[2], (unsigned long long)es[3]);
+        for (int k = 0; k < 20; k++) { if (g_secn[k]) { printf("sec %d: %llu cycles / %u = %llu\n", k, g_sec[k], g_secn[k], g_sec[k] / g_secn[k]); } }
         printf("emit slow: lit insert %u/%llu changed %u/%llu; pos insert %u/%llu changed %u/%llu\n",
                lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1],
                pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1]);
@@ -385,7 +390,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     if (lane == 0) {
         out_bytes[b] = q.bytes;
         err_out[b] = err;
-        if (stats_out != nullptr) {
+        if (kStats && stats_out != nullptr) {
             sqz_block_stats st;
             st.lit_updates = lit.stats.updates; st.lit_swaps = lit.stats.swaps; st.lit_moves = lit.stats.moves;
             st.pos_updates = pos.stats.updates; st.pos_swaps = pos.stats.swaps; st.pos_moves = pos.stats.moves;
@@ -396,7 +401,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         }
     }
     // leaf counts for huffman_entropy (huffman.h:237-249; the host does the logarithms)
-    if (stats_out != nullptr) {
+    if (kStats && stats_out != nullptr) {
         for (int k = lane; k < kLitLeaves; k += kWave) { stats_out[b].lit_freq[k] = lit.freq(k); }
         if (lane < kPosLeaves) { stats_out[b].pos_freq[lane] = pos.freq(kPosBase + lane); }
     }
@@ -409,8 +414,10 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 // (tests/golden/trees.npz, huffman.h node arrays) pin the device tree directly.
 // dump layout (uint32): [0..7] next, depth mark, complete, aux, fault, updates, swaps, moves;
 // then per node id v of the tree (NODES of them): lnk, rng, cnt, code (leaves; 0 otherwise).
+using DbgLit = LitTreeT<true, true>;
+using DbgPos = PosTreeT<true, true>;
 template <class T>
-__device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, EmitLds& lds, const int32_t* symbols,
+__device__ __forceinline__ void debug_drive(T& t, DbgLit& lit, DbgPos& pos, EmitLds& lds, const int32_t* symbols,
                                             uint32_t count, int batch, int lane, bool is_pos, bool stop_early,
                                             uint32_t max_steps, uint32_t& consumed) {
     uint32_t k = 0;
@@ -442,12 +449,12 @@ __device__ __forceinline__ void debug_drive(T& t, LitTree& lit, PosTree& pos, Em
     consumed = k;
 }
 
-__global__ __launch_bounds__(kWave)
+__global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
 void tree_debug_kernel(const int32_t* __restrict__ symbols, uint32_t count, int which, int batch,
                        uint32_t* __restrict__ dump) {
     __shared__ EmitLds lds;
     const int lane = threadIdx.x;
-    LitTree lit; PosTree pos;
+    DbgLit lit; DbgPos pos;
     lit.lds = &lds.tree; lit.code = lds.code; lit.lut = nullptr;
     pos.lds = &lds.tree; pos.code = lds.code; pos.lut = nullptr;
     lit.init_all(lane);
@@ -495,9 +502,15 @@ void launch_huffman_emit(const uint32_t* tokens, const uint64_t* tok_off,
                          uint64_t prefix_acc, int prefix_fill, sqz_block_stats* stats,
                          hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(huffman_emit_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       tokens, tok_off, tok_count, out, out_off, out_bytes, err, n_blocks,
-                       prefix_acc, prefix_fill, stats);
+    if (stats != nullptr) {
+        hipLaunchKernelGGL(huffman_emit_kernel<true>, dim3(n_blocks), dim3(kWave), 0, stream,
+                           tokens, tok_off, tok_count, out, out_off, out_bytes, err, n_blocks,
+                           prefix_acc, prefix_fill, stats);
+    } else {
+        hipLaunchKernelGGL(huffman_emit_kernel<false>, dim3(n_blocks), dim3(kWave), 0, stream,
+                           tokens, tok_off, tok_count, out, out_off, out_bytes, err, n_blocks,
+                           prefix_acc, prefix_fill, stats);
+    }
 }
 
 } // namespace sqzk

@@ -101,6 +101,16 @@ constexpr int kTokenBits = 2 * (kAuxDepth - 1) + 18;
 constexpr int kPackWords = (63 + 58 + kWave * kTokenBits + 63) / 64 + 1;     // carry + pending + 64 tokens
 constexpr int kImageWords = kPackWords > kWave ? kPackWords : kWave;         // (the histogram takes 64 words)
 
+#if defined(SQZ_STATS) && defined(SQZ_SEC_TIMERS)
+__device__ unsigned long long g_sec[32];
+__device__ unsigned int g_secn[32];
+#define SEC_BEGIN uint64_t sec_t_ = __builtin_readcyclecounter();
+#define SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); if (blockIdx.x == 1 && threadIdx.x == 0) { g_sec[k] += n_ - sec_t_; g_secn[k]++; } sec_t_ = n_; }
+#else
+#define SEC_BEGIN
+#define SEC(k)
+#endif
+
 struct TreeLds {
     uint32_t lnk[kAllNodes];
     uint32_t rng[kAllNodes];
@@ -136,16 +146,20 @@ __device__ __forceinline__ uint32_t r_first(uint32_t w) { return w & 0x3FFu; }
 __device__ __forceinline__ uint32_t r_last(uint32_t w) { return (w >> 10) & 0x3FFu; }
 __device__ __forceinline__ uint32_t r_pa(uint32_t w) { return (w >> 20) & 0x3FFu; }
 constexpr uint32_t kEndsMask = 0xFFFFFu;      // everything below the partner
+constexpr uint32_t kNoPos = 0x1FFu;           // position field of a leaf that is not in the tree
 __device__ __forceinline__ uint32_t c_f(uint32_t w) { return w & kCountMask; }
 __device__ __forceinline__ uint32_t c_d(uint32_t w) { return (w >> kDepthShift) & 0x3Fu; }
 
+// maximum over the wave: the same six DPP steps as wave_scan, the total ends up in lane 63
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)v, o);
-        v = other > v ? other : v;
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, kWave - 1);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -172,7 +186,7 @@ template <class T> __device__ __noinline__ void slow_build_lut(const uint32_t* l
 // emitted bit depends on it); REF_LEAVES: the reference's leaf count n (512 / 32, squeeze.h:204-205),
 // which only fixes how many leaf splits huffman_insert allows (n - 2, huffman.h:180); POS0: first
 // leaf position; LUT_BITS: the decoder's lookup table width.
-template <int BASE, int LEAVES, int NODES, int REF_LEAVES, int POS0, int LUT_BITS, bool CODES>
+template <int BASE, int LEAVES, int NODES, int REF_LEAVES, int POS0, int LUT_BITS, bool CODES, bool STATS>
 struct Tree {
     TreeLds* lds;
     uint32_t* code;     // encoder only (CODES): kCodeSlots entries
@@ -184,6 +198,7 @@ struct Tree {
     int fault;          // stack / depth guard (never set for realistic streams)
     int aux;            // leaf positions / ends / partners / codes are kept (tree shallower than kAuxDepth so far)
     int lut_ok;         // decoder: the lookup table matches the tree
+    int in_insert;      // between a leaf split and the closing walk of huffman_insert the depth mark may lag behind
     TreeStats stats;
 
     static constexpr int kBase = BASE;
@@ -197,10 +212,10 @@ struct Tree {
     __device__ __forceinline__ void init_all(int lane) {      // huffman.h:251-269
         for (int i = BASE + lane; i < BASE + NODES; i += kWave) {
             lds->lnk[i] = 0x3FFFFFFFu;
-            lds->rng[i] = kNil << 20;
+            lds->rng[i] = kNoPos | (kNil << 20);               // a leaf outside the tree is at no position
             lds->cnt[i] = 0;
         }
-        next = kRoot + 1; depth = 0; complete = 0; fault = 0; aux = 1; lut_ok = 0;
+        next = kRoot + 1; depth = 0; complete = 0; fault = 0; aux = 1; lut_ok = 0; in_insert = 0;
         stats.updates = stats.swaps = stats.moves = 0;
     }
 
@@ -263,23 +278,25 @@ struct Tree {
     // [a, b).  The walk visits every node of the subtree once (huffman.h:42): 2 * leaves - 1 of them.
     __device__ __forceinline__ void mark_range(int top, uint32_t a, uint32_t b, uint32_t deepest_known, int lane) {
         uint32_t deepest = deepest_known;
-        if (deepest_known == 0) {
+        // At rest the mark is at least the depth of every node (a walk from the root sets it to the true
+        // maximum, every later walk raises it to what it saw): a walk over unchanged depths cannot move it,
+        // except from the root (restart) and inside huffman_insert (the split's new level is not in it yet).
+        if (deepest_known == 0 && (top == kRoot || in_insert != 0)) {
 #pragma unroll
             for (int r = 0; r < kLeafRows; r++) {
                 const int v = BASE + r * kWave + lane;
-                const uint32_t d = c_d(lds->cnt[v < kRoot ? v : kRoot]);
-                const uint32_t q = r_pos(lds->rng[v < kRoot ? v : kRoot]);
-                const bool in = v < kRoot && d != 0 && q >= a && q < b;
+                if (BASE + r * kWave >= kRoot) { break; }
+                const int vv = v < kRoot ? v : kRoot;
+                const uint32_t q = r_pos(lds->rng[vv]);
+                const uint32_t d = c_d(lds->cnt[vv]);
+                const bool in = v < kRoot && q >= a && q < b;
                 deepest = (in && d > deepest) ? d : deepest;
             }
             deepest = wave_max(deepest);
         }
-#ifdef SQZ_DEBUG_TREE
-        if (lane == 0) { printf("relabel visited=%u top=%d [%u,%u)\n", 2u * (b - a) - 1u, top, a, b); }
-#endif
         if (top == kRoot) { depth = 0; }
         raise_mark((int)deepest, lane);
-        stats.updates += 2u * (b - a) - ((uint32_t)top == (uint32_t)kRoot && l_lo(lds->lnk[kRoot]) == kNil ? 0u : 1u);
+        if (STATS) { stats.updates += 2u * (b - a) - ((uint32_t)top == (uint32_t)kRoot && l_lo(lds->lnk[kRoot]) == kNil ? 0u : 1u); }
     }
     __device__ __forceinline__ void mark_subtree(int top, int lane) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(first_leaf((uint32_t)top)));
@@ -322,9 +339,11 @@ struct Tree {
     // lo slot (its leaves, positions [m, b), come first from now on), Y = the child now hi (was
     // [a, m)).  Leaf positions move, one code bit of every leaf below p flips, p's ends and the
     // tests of X and Y follow; the depth mark and the statistics see the walk
-    // huffman_swap_siblings makes (huffman.h:76-80).  dp = depth of p.
-    __device__ __forceinline__ void swap_fix(int p, uint32_t dp, int lane) {
-        stats.swaps += 1;
+    // huffman_swap_siblings makes (huffman.h:76-80).  dp = depth of p; fX..lY = first / last leaf of X
+    // and Y; y_partner = the sibling of p (Y's uncle from now on; kNil when p is the root).
+    __device__ __forceinline__ void swap_fix(int p, uint32_t dp, uint32_t X, uint32_t Y, uint32_t fX, uint32_t lX,
+                                             uint32_t fY, uint32_t lY, uint32_t y_partner, int lane) {
+        if (STATS) { stats.swaps += 1; }
         if (aux == 0) {                                        // wide mode: the reference's walk, one lane
             if (lane == 0) { relabel(p); }
             uniform_regs();
@@ -332,43 +351,54 @@ struct Tree {
             return;
         }
         // (read by one lane and broadcast: the pass below rewrites positions)
-        const uint32_t pw = lds->lnk[p];
-        const uint32_t X = l_lo(pw), Y = l_hi(pw);
-        const uint32_t fX = first_leaf(X), lX = last_leaf(X), fY = first_leaf(Y), lY = last_leaf(Y);
         const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fY));
         const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fX));
         const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lX)) + 1u;
-#ifdef SQZ_DEBUG_TREE
-        if (lane == 0) { printf("swap p=%d dp=%u X=%u Y=%u a=%u m=%u b=%u\n", p, dp, X, Y, a, m, b); }
-#endif
+        const bool want_depth = p == kRoot || in_insert != 0;
         uint32_t deepest = 0;
 #pragma unroll
         for (int r = 0; r < kLeafRows; r++) {
             const int v = BASE + r * kWave + lane;
             if (BASE + r * kWave >= kRoot) { break; }
-            const int vv = v < kRoot ? v : kRoot;
-            const uint32_t w = lds->rng[vv], d = c_d(lds->cnt[vv]);
+            const uint32_t w = lds->rng[v < kRoot ? v : kRoot - 1];
             const uint32_t q = r_pos(w);
-            const bool live = v < kRoot && d != 0;
-            const bool in_x = live && q >= m && q < b, in_y = live && q >= a && q < m;
+            const bool in_x = v < kRoot && q >= m && q < b, in_y = v < kRoot && q >= a && q < m;
             if (in_x | in_y) {
                 lds->rng[v] = (w & ~0x1FFu) | (in_x ? q - (m - a) : q + (b - m));
-                if (CODES) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
-                deepest = d > deepest ? d : deepest;
+                if (CODES | want_depth) {
+                    const uint32_t d = c_d(lds->cnt[v]);
+                    if (CODES) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
+                    deepest = d > deepest ? d : deepest;
+                }
             }
         }
-        if (lane == 0) { set_ends(p, fX, lY); }
+        if (lane == 0) {
+            set_ends(p, fX, lY);
+            lds->rng[X] = (lds->rng[X] & kEndsMask) | (Y << 20);          // a lo child is tested against its sibling
+            lds->rng[Y] = (lds->rng[Y] & kEndsMask) | (y_partner << 20);  // a hi child against its uncle
+        }
         lds_fence();
-        fix_partners(p, 1, lane);
-        mark_range(p, a, b, wave_max(deepest), lane);
+        mark_range(p, a, b, want_depth ? wave_max(deepest) : 0u, lane);
+    }
+    // the same when the caller knows nothing but p (rare: the order checks of a promotion, the root's pair)
+    __device__ __forceinline__ void swap_fix_at(int p, uint32_t dp, int lane) {
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->lnk[p]);
+        const uint32_t X = l_lo(pw), Y = l_hi(pw);
+        uint32_t unc = kNil;
+        if (l_up(pw) != kNil) {
+            const uint32_t gw = lds->lnk[l_up(pw)];
+            unc = l_lo(gw) == (uint32_t)p ? l_hi(gw) : l_lo(gw);
+        }
+        swap_fix(p, dp, X, Y, first_leaf(X), last_leaf(X), first_leaf(Y), last_leaf(Y), unc, lane);
     }
 
     // c (hi child of p) and its uncle u have traded places under g (the links already say so):
     //   left  (p = lo(g)):  [x][c][u] -> [x][u][c]      c: G01S -> G1S     u: G1S -> G01S
     //   right (p = hi(g)):  [u][x][c] -> [c][x][u]      c: G11S -> G0S     u: G0S -> G11S
     // (G = the code of g, dg bits; S = what follows below the moved node).  c's leaves come up a level.
-    __device__ __forceinline__ void promote_fix(int g, uint32_t dg, int p, int c, int u, int left, int lane) {
-        stats.moves += 1;
+    __device__ __forceinline__ void promote_fix(int g, uint32_t dg, int p, int c, int u, int left,
+                                                uint32_t& ga, uint32_t& gb, uint32_t& deepest_out, int lane) {
+        if (STATS) { stats.moves += 1; }
         if (aux == 0) { return; }
         const uint32_t x = l_lo(lds->lnk[p]);
         const uint32_t fc = first_leaf((uint32_t)c), lc = last_leaf((uint32_t)c), fu = first_leaf((uint32_t)u);
@@ -384,18 +414,23 @@ struct Tree {
 #endif
         const int C = (int)(cb - ca), U = (int)(ub - ua), X = (int)(xb - xa);
         const int dc = left ? U : -(U + X), du = left ? -C : C + X, dx = left ? 0 : C - U;
+        ga = left ? xa : ua;                                   // g's leaves: the three runs are neighbours
+        gb = ga + (uint32_t)(C + U + X);
+        uint32_t deepest = 0;
 #pragma unroll
         for (int r = 0; r < kLeafRows; r++) {
             const int v = BASE + r * kWave + lane;
             if (BASE + r * kWave >= kRoot) { break; }
-            const int vv = v < kRoot ? v : kRoot;
+            const int vv = v < kRoot ? v : kRoot - 1;
             const uint32_t w = lds->rng[vv], cw = lds->cnt[vv];
             const uint32_t q = r_pos(w), d = c_d(cw);
-            const bool live = v < kRoot && d != 0;
+            const bool live = v < kRoot;                         // (a leaf outside the tree is at no position)
             const bool in_c = live && q >= ca && q < cb, in_u = live && q >= ua && q < ub, in_x = live && q >= xa && q < xb;
             if (in_c | in_u | in_x) {
                 const int shift = in_c ? dc : in_u ? du : dx;
                 lds->rng[v] = (w & ~0x1FFu) | (uint32_t)((int)q + shift);
+                const uint32_t nd = in_c ? d - 1u : in_u ? d + 1u : d;
+                deepest = nd > deepest ? nd : deepest;
                 if (in_c | in_u) {
                     lds->cnt[v] = in_c ? cw - (1u << kDepthShift) : cw + (1u << kDepthShift);
                     if (CODES) {
@@ -415,6 +450,7 @@ struct Tree {
         }
         lds_fence();
         fix_partners(g, 3, lane);
+        deepest_out = wave_max(deepest);
     }
 
     // ---------------- the reference sequence on one lane (wide mode / deep trees) ----------------
@@ -435,7 +471,7 @@ struct Tree {
             if (guard >= NODES) { fault = 1; break; }            // more visits than nodes: the links are corrupt
             const uint32_t e = lds->lvl[--sp];
             const int v = (int)(e & 0x3FFu), b = (int)(e >> 10);
-            stats.updates += 1;
+            if (STATS) { stats.updates += 1; }
             if (b > depth) { depth = b; }
             if (v < kRoot) { continue; }
             if (b >= 62) { fault = 1; continue; }               // reference asserts bits < 63
@@ -455,7 +491,7 @@ struct Tree {
         const uint32_t w = lds->lnk[p];
         const uint32_t l = l_lo(w), r = l_hi(w);
         if (l != kNil && r != kNil && freq((int)l) > freq((int)r)) {
-            stats.swaps += 1;
+            if (STATS) { stats.swaps += 1; }
             lds->lnk[p] = mk_lnk(l_up(w), r, l);
             relabel((int)p);
             return i == (int)l ? (int)r : (int)l;
@@ -492,7 +528,7 @@ struct Tree {
             const bool left = l_lo(gw) == (uint32_t)p;
             const int uncle = (int)(left ? l_hi(gw) : l_lo(gw));
             if (!(freq(c) > freq(uncle))) { continue; }                       // :108
-            stats.moves += 1;
+            if (STATS) { stats.moves += 1; }
             lds->lnk[c] = (lds->lnk[c] & ~0x3FFu) | (uint32_t)g;
             lds->lnk[g] = left ? mk_lnk(l_up(gw), l_lo(gw), (uint32_t)c) : mk_lnk(l_up(gw), (uint32_t)c, l_hi(gw));
             lds->lnk[p] = mk_lnk(l_up(pw), l_lo(pw), (uint32_t)uncle);
@@ -543,17 +579,30 @@ struct Tree {
         if (swap) {
             if (lane == 0) { lds->lnk[p] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
             lds_fence();
-            swap_fix((int)p, dp, lane);
+            swap_fix_at((int)p, dp, lane);
         }
     }
+
+    // What a climb leaves in every lane's registers: enough to pick and carry out the promotion the
+    // reference would try next (huffman.h:143-146, :98-109) without reading the tree again.
+    struct Climbed {
+        uint64_t hits;      // lanes whose pending pair passes both tests of move_up
+        int ch;             // the pair's child: my node, or its sibling after an exchange (huffman.h:81)
+        uint32_t fch;       // ... its count
+        uint32_t fpar;      // my parent's refreshed count
+        int sib;            // my node's sibling before the exchange
+        uint32_t fs;        // ... its count
+        bool ends_hi;       // my node ends up as the hi child
+    };
 
     // The climb of huffman_frequency_changed (huffman.h:132-142) along the chain `c` from its level
     // k0 upwards: lane k >= k0 owns the edge from level k to its parent; new sums by prefix sum,
     // sibling order per level, the parents' first / last leaves, one pending pair per level (bottom
-    // first, appended at pend[sp]).
-    __device__ __forceinline__ int climb_wave(const Chain& c, int k0, int sp, int lane) {
+    // first, appended at pend[sp]) -- and, in registers, which of those pairs would be promoted.
+    __device__ __forceinline__ int climb_wave(const Chain& c, int k0, int sp, bool ends_moved, Climbed& out, int lane) {
         const int levels = c.levels;
         const int span = levels - k0;
+        out.hits = 0;
         if (levels >= kMaxFastDepth || sp + span > kWave) { fault = 1; return 0; }
         const int start = __builtin_amdgcn_readlane(c.mine, k0);
         if (span <= 0) {                                              // the start node is the root
@@ -573,14 +622,32 @@ struct Tree {
         const uint32_t incl = wave_scan(act ? fs : 0u);
         const uint32_t fx = f0 + incl - fs;                          // my node's count, refreshed
         const bool swap = has_sib & (is_hi ? (fs > fx) : (fx > fs));  // lo count > hi count
+        const uint64_t swaps = __ballot(swap);
+        const bool ends_hi = act & (is_hi != swap);
+        out.ch = swap ? (int)sib : x;
+        out.fch = swap ? fs : fx;
+        out.fpar = f0 + incl;
+        out.sib = (int)sib;
+        out.fs = fs;
+        out.ends_hi = ends_hi;
+        // move_up's tests for the pair of this level (huffman.h:143, :108): the pair's child is the hi
+        // child (after an exchange the OTHER sibling is carried on, and it is hi exactly when my node
+        // was), its parent is not the root, and it outweighs its uncle = the sibling one level up
+        {
+            const uint32_t f_unc = (uint32_t)lane_above((int)fs);
+            const bool has_unc = lane_above(has_sib ? 1 : 0) == 1;
+            out.hits = __ballot(act & is_hi & (lane + 1 < levels) & has_unc & (out.fch > f_unc));
+        }
         // first / last leaf of every parent on the chain: the first leaf of level k+1 is the sibling's
-        // where x ends up as the hi child, else what came up from below; the last leaf the other way round
-        uint32_t ends = 0;
-        if (aux != 0) {
-            const bool ends_hi = act & (is_hi != swap);
+        // where x ends up as the hi child, else what came up from below; the last leaf the other way
+        // round.  They only move when a pair was exchanged here or the start node's own ends did
+        // (ends_moved: the climb follows a promotion or an insert).
+        uint32_t sF = 0, sL = 0, ends = 0;
+        const bool redo_ends = aux != 0 && (swaps != 0 || ends_moved);
+        if (redo_ends) {
             const uint32_t sw = has_sib ? lds->rng[sib] : 0u;
-            const uint32_t sF = has_sib ? (is_leaf(sib) ? sib : r_first(sw)) : (uint32_t)x;
-            const uint32_t sL = has_sib ? (is_leaf(sib) ? sib : r_last(sw)) : (uint32_t)x;
+            sF = has_sib ? (is_leaf(sib) ? sib : r_first(sw)) : (uint32_t)x;
+            sL = has_sib ? (is_leaf(sib) ? sib : r_last(sw)) : (uint32_t)x;
             const uint32_t F0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_leaf((uint32_t)start));
             const uint32_t L0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)last_leaf((uint32_t)start));
             const uint64_t below = (2ull << lane) - 1ull;             // lanes <= mine
@@ -593,90 +660,155 @@ struct Tree {
         if (act) {
             lds->cnt[p] = aux != 0 ? ((f0 + incl) & kCountMask) : (f0 + incl);
             if (swap) { lds->lnk[p] = mk_lnk(l_up(pw), l_hi(pw), l_lo(pw)); }
-            if (aux != 0) { lds->rng[p] = (lds->rng[p] & ~kEndsMask) | ends; }
-            lds->pend[sp + lane - k0] = ((uint32_t)p << 16) | (swap ? sib : (uint32_t)x);
+            if (redo_ends) { lds->rng[p] = (lds->rng[p] & ~kEndsMask) | ends; }
+            lds->pend[sp + lane - k0] = ((uint32_t)p << 16) | (uint32_t)out.ch;
         }
         lds_fence();
-        uint64_t swaps = __ballot(swap);
-        while (swaps != 0) {                                          // rare: one pass per exchanged pair
-            const int k = __builtin_ctzll(swaps);
-            swaps &= swaps - 1;
-            swap_fix(__builtin_amdgcn_readlane(p, k), (uint32_t)(levels - k - 1), lane);
+        if (swaps != 0) {                                             // rare: one pass per exchanged pair
+            // my node's own ends: what the lane below computed for its parent (= my node), or the start's
+            const uint32_t below_ends = (uint32_t)lane_below((int)ends);
+            const uint32_t xF = lane == k0 ? first_leaf((uint32_t)x) : (below_ends & 0x3FFu);
+            const uint32_t xL = lane == k0 ? last_leaf((uint32_t)x) : ((below_ends >> 10) & 0x3FFu);
+            const uint32_t unc = (uint32_t)lane_above((int)sib);      // my parent's sibling (kNil above the chain)
+            uint64_t todo = swaps;
+            while (todo != 0) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                // after the exchange the lo slot holds the old hi child
+                const bool x_hi = __builtin_amdgcn_readlane(ends_hi ? 1 : 0, k) != 0;
+                const uint32_t xk = (uint32_t)__builtin_amdgcn_readlane(x, k), sk = (uint32_t)__builtin_amdgcn_readlane((int)sib, k);
+                const uint32_t xFk = (uint32_t)__builtin_amdgcn_readlane((int)xF, k), xLk = (uint32_t)__builtin_amdgcn_readlane((int)xL, k);
+                const uint32_t sFk = (uint32_t)__builtin_amdgcn_readlane((int)sF, k), sLk = (uint32_t)__builtin_amdgcn_readlane((int)sL, k);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(p, k);
+                const uint32_t uk = k + 1 < levels ? (uint32_t)__builtin_amdgcn_readlane((int)unc, k) : kNil;
+                if (x_hi) { swap_fix((int)pk, (uint32_t)(levels - k - 1), sk, xk, sFk, sLk, xFk, xLk, uk, lane); }
+                else      { swap_fix((int)pk, (uint32_t)(levels - k - 1), xk, sk, xFk, xLk, sFk, sLk, uk, lane); }
+            }
         }
         return sp + span;
     }
 
-    // huffman_frequency_changed + move_up along the chain `c` of the node whose count changed.  The
-    // chain stays valid throughout: a promotion under g changes nothing above g, and the climb that
-    // follows it starts at g.
-    __device__ __forceinline__ void changed_all(const Chain& c_in, int lane) {
-        Chain c = c_in;
-        int valid_from = 0;                                           // lanes of `c` from here up are a true root path
-        int sp = climb_wave(c, 0, 0, lane);
-        // (a promotion moves a node up, so a symbol's update makes fewer of them than the tree is
-        // deep; the bound only keeps a wave from spinning on a corrupted tree: it faults instead)
-        for (int guard = 0; sp > 0; guard++) {
-            if (guard >= 4 * kWave) { fault = 1; break; }
-            // every pending pair at once: the reference pops them from the top and the
-            // ones that fail its tests (:143, :108) change nothing
-            bool hit = false;
-            int p = 0, ch = 0, g = 0, uncle = 0, left = 0;
-            if (lane < sp) {
-                const uint32_t e = lds->pend[lane];
-                p = (int)(e >> 16); ch = (int)(e & 0xFFFFu);
-                const uint32_t pw = lds->lnk[p];
-                if (l_up(pw) != kNil && l_hi(pw) == (uint32_t)ch) {
-                    g = (int)l_up(pw);
-                    const uint32_t gw = lds->lnk[g];
-                    left = l_lo(gw) == (uint32_t)p ? 1 : 0;
-                    uncle = (int)(left ? l_hi(gw) : l_lo(gw));
-                    hit = uncle != (int)kNil && freq(ch) > freq(uncle);
-                }
-            }
-            const uint64_t hits = __ballot(hit);
-            if (hits == 0) { break; }
-            const int j = 63 - __builtin_clzll(hits);
-            sp = j;
-            p = __builtin_amdgcn_readlane(p, j);
-            ch = __builtin_amdgcn_readlane(ch, j);
-            g = __builtin_amdgcn_readlane(g, j);
-            uncle = __builtin_amdgcn_readlane(uncle, j);
-            left = __builtin_amdgcn_readlane(left, j);
-            // g's level on the chain (the lane holding it) gives its depth and where the next climb
-            // starts.  A promotion leaves the chain ABOVE its g intact; a later hit further down (an
-            // older pending pair) finds its g off the intact part: take g's root path afresh then.
-            const uint64_t at_g = __ballot(c.holds && c.mine == g && lane >= valid_from);
-            int kg = 0;
-            if (at_g != 0) { kg = __builtin_ctzll(at_g); }
-            else { c = chain_up(g, lane); }
-            valid_from = kg;
-            const uint32_t dg = (uint32_t)(c.levels - kg);
-            if (lane == 0) {                                          // move_up, :110-119
-                lds->lnk[ch] = (lds->lnk[ch] & ~0x3FFu) | (uint32_t)g;
-                const uint32_t gw = lds->lnk[g];
-                lds->lnk[g] = left ? mk_lnk(l_up(gw), l_lo(gw), (uint32_t)ch) : mk_lnk(l_up(gw), (uint32_t)ch, l_hi(gw));
-                const uint32_t pw = lds->lnk[p];
-                lds->lnk[p] = mk_lnk(l_up(pw), l_lo(pw), (uint32_t)uncle);
-                lds->lnk[uncle] = (lds->lnk[uncle] & ~0x3FFu) | (uint32_t)p;
-            }
+    // move_up (huffman.h:110-125) for the pair (p, ch) under g with uncle `uncle`; fch / func / fpar =
+    // the counts of ch, of the uncle and of p (refreshed) before the move; dg = depth of g.
+    __device__ __forceinline__ void promote(int g, uint32_t dg, int p, int ch, int uncle, int left,
+                                            uint32_t fch, uint32_t func, uint32_t fpar, int lane) {
+        if (lane == 0) {                                              // :110-119, and p's new sum (:120; g's does not change)
+            const uint32_t cw = lds->lnk[ch], gw = lds->lnk[g], pw = lds->lnk[p], uw = lds->lnk[uncle];
+            lds->lnk[ch] = (cw & ~0x3FFu) | (uint32_t)g;
+            lds->lnk[g] = left ? mk_lnk(l_up(gw), l_lo(gw), (uint32_t)ch) : mk_lnk(l_up(gw), (uint32_t)ch, l_hi(gw));
+            lds->lnk[p] = mk_lnk(l_up(pw), l_lo(pw), (uint32_t)uncle);
+            lds->lnk[uncle] = (uw & ~0x3FFu) | (uint32_t)p;
+            lds->cnt[p] += func - fch;
+        }
+        lds_fence();
+        uint32_t ga = 0, gb = 0, deepest = 0;
+        promote_fix(g, dg, p, ch, uncle, left, ga, gb, deepest, lane);
+        // :122-124, the three order checks: ch and p under g, x and the uncle under p, p under g again
+        // (the same pair as the first: nothing left to do).  All counts are known.
+        const uint32_t f_x = fpar - fch, f_p = f_x + func;
+        const bool swap_g = left ? (f_p > fch) : (fch > f_p);
+        const bool swap_p = f_x > func;
+        if (swap_g) {
+            if (lane == 0) { const uint32_t w = lds->lnk[g]; lds->lnk[g] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
             lds_fence();
-            promote_fix(g, dg, p, ch, uncle, left, lane);
-            if (lane == 0) { sum(p); sum(g); }                        // :120-121
+            swap_fix_at(g, dg, lane);
+        }
+        if (swap_p) {
+            if (lane == 0) { const uint32_t w = lds->lnk[p]; lds->lnk[p] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
             lds_fence();
-            order_only(ch, dg, lane);                                 // :122-124 (ch hangs under g now)
-            order_only(uncle, dg + 1u, lane);                         //          (the uncle under p)
-            order_only(p, dg, lane);
-            if (aux != 0) {
-                // an exchange under p moved p's ends: g's follow (everything above g is redone by the climb)
+            swap_fix_at(p, dg + 1u, lane);
+        }
+        if (aux != 0) {
+            if (swap_p) {                                             // p's ends moved: g's follow (the climb redoes everything above g)
                 if (lane == 0) {
                     const uint32_t gw = lds->lnk[g];
                     set_ends(g, first_leaf(l_lo(gw)), last_leaf(l_hi(gw)));
                 }
                 lds_fence();
-                mark_subtree(g, lane);                                // :125 huffman_update_paths(gix)
             }
-            else { if (lane == 0) { relabel(g); } uniform_regs(); lds_fence(); }
-            sp = climb_wave(c, kg, sp, lane);                         // :126
+            mark_range(g, ga, gb, deepest, lane);                     // :125 huffman_update_paths(gix)
+        } else {
+            if (lane == 0) { relabel(g); }
+            uniform_regs();
+            lds_fence();
+        }
+    }
+
+    // huffman_frequency_changed + move_up along the chain `c` of the node whose count changed.  The
+    // chain stays valid throughout: a promotion under g changes nothing above g, and the climb that
+    // follows it starts at g.  Pending pairs: pend[0, base) are older ones (below the last promotion),
+    // pend[base, sp) the ones of the latest climb, already judged in registers.
+    __device__ __forceinline__ void changed_all(const Chain& c_in, int lane) {
+        Chain c = c_in;
+        Climbed r;
+        int valid_from = 0;                                           // lanes of `c` from here up are a true root path
+        int k0 = 0, base = 0;
+        int sp = climb_wave(c, 0, 0, in_insert != 0, r, lane);
+        // (a promotion moves a node up, so a symbol's update makes fewer of them than the tree is
+        // deep; the bound only keeps a wave from spinning on a corrupted tree: it faults instead)
+        for (int guard = 0; sp > 0; guard++) {
+            if (guard >= 4 * kWave) { fault = 1; break; }
+            int p, ch, g, uncle, left, kg;
+            uint32_t fch, func, fpar;
+            if (r.hits != 0) {
+                // the topmost pair of the latest climb that passes (the reference pops from the top; the
+                // ones that fail its tests change nothing): everything is in registers
+                const int j = 63 - __builtin_clzll(r.hits);
+                p = __builtin_amdgcn_readlane(c.par, j);
+                ch = __builtin_amdgcn_readlane(r.ch, j);
+                fch = (uint32_t)__builtin_amdgcn_readlane((int)r.fch, j);
+                fpar = (uint32_t)__builtin_amdgcn_readlane((int)r.fpar, j);
+                g = __builtin_amdgcn_readlane(c.par, j + 1);
+                uncle = __builtin_amdgcn_readlane(r.sib, j + 1);
+                func = (uint32_t)__builtin_amdgcn_readlane((int)r.fs, j + 1);
+                left = __builtin_amdgcn_readlane(r.ends_hi ? 1 : 0, j + 1) != 0 ? 0 : 1;
+                kg = j + 2;
+                sp = base + (j - k0);
+            } else {
+                // none of them: they are popped; then the older pairs, from the tree (rare)
+                sp = base;
+                if (sp == 0) { break; }
+                bool hit = false;
+                int hp = 0, hc = 0, hg = 0, hu = 0, hl = 0;
+                uint32_t h_fch = 0, h_func = 0, h_fpar = 0;
+                if (lane < sp) {
+                    const uint32_t e = lds->pend[lane];
+                    hp = (int)(e >> 16); hc = (int)(e & 0xFFFFu);
+                    const uint32_t pw = lds->lnk[hp];
+                    if (l_up(pw) != kNil && l_hi(pw) == (uint32_t)hc) {
+                        hg = (int)l_up(pw);
+                        const uint32_t gw = lds->lnk[hg];
+                        hl = l_lo(gw) == (uint32_t)hp ? 1 : 0;
+                        hu = (int)(hl ? l_hi(gw) : l_lo(gw));
+                        if (hu != (int)kNil) {
+                            h_fch = freq(hc); h_func = freq(hu); h_fpar = freq(hp);
+                            hit = h_fch > h_func;
+                        }
+                    }
+                }
+                const uint64_t hits = __ballot(hit);
+                if (hits == 0) { break; }
+                const int j = 63 - __builtin_clzll(hits);
+                sp = j;
+                p = __builtin_amdgcn_readlane(hp, j); ch = __builtin_amdgcn_readlane(hc, j);
+                g = __builtin_amdgcn_readlane(hg, j); uncle = __builtin_amdgcn_readlane(hu, j);
+                left = __builtin_amdgcn_readlane(hl, j);
+                fch = (uint32_t)__builtin_amdgcn_readlane((int)h_fch, j);
+                func = (uint32_t)__builtin_amdgcn_readlane((int)h_func, j);
+                fpar = (uint32_t)__builtin_amdgcn_readlane((int)h_fpar, j);
+                // g's level on the chain gives its depth and where the next climb starts.  A promotion
+                // leaves the chain ABOVE its g intact; this older pair may sit off the intact part: take
+                // g's root path afresh then.
+                const uint64_t at_g = __ballot(c.holds && c.mine == g && lane >= valid_from);
+                kg = 0;
+                if (at_g != 0) { kg = __builtin_ctzll(at_g); }
+                else { c = chain_up(g, lane); }
+            }
+            valid_from = kg;
+            base = sp;
+            promote(g, (uint32_t)(c.levels - kg), p, ch, uncle, left, fch, func, fpar, lane);
+            k0 = kg;
+            sp = climb_wave(c, kg, sp, true, r, lane);                // :126
         }
     }
 
@@ -750,10 +882,12 @@ struct Tree {
 
     // the slow calls leave what they counted in pend[61..63] (nothing is pending between calls)
     __device__ __forceinline__ void store_stats_delta(int lane) {
+        if (!STATS) { return; }
         if (lane == 0) { lds->pend[61] = stats.updates; lds->pend[62] = stats.swaps; lds->pend[63] = stats.moves; }
         lds_fence();
     }
     __device__ __forceinline__ void load_stats_delta() {
+        if (!STATS) { return; }
         stats.updates += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[61]);
         stats.swaps += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[62]);
         stats.moves += (uint32_t)__builtin_amdgcn_readfirstlane((int)lds->pend[63]);
@@ -846,7 +980,7 @@ struct Tree {
                 if (BASE + r * kWave >= kRoot) { break; }
                 const int vv = v < kRoot ? v : kRoot;
                 const uint32_t w = lds->rng[vv];
-                if (v < kRoot && v != i && c_d(lds->cnt[vv]) != 0 && r_pos(w) > q) { lds->rng[v] = w + 1u; }
+                if (v < kRoot && v != i && r_pos(w) != kNoPos && r_pos(w) > q) { lds->rng[v] = w + 1u; }
             }
             if (lane == 0) {
                 lds->rng[i] = (q + 1u) | (kNil << 20);
@@ -867,7 +1001,7 @@ struct Tree {
                 if (lane == 0) { lds->lnk[at] = mk_lnk(l_up(w), l_hi(w), l_lo(w)); }
                 lds_fence();
                 start = start == (int)l_lo(w) ? (int)l_hi(w) : (int)l_lo(w);
-                swap_fix(at, droot, lane);
+                swap_fix_at(at, droot, lane);
             }
         }
         if (depth + 4 >= kMaxFastDepth) {                              // chains longer than the wave: the reference sequence on one lane
@@ -877,9 +1011,11 @@ struct Tree {
             lds_fence();
         } else {
             const Chain c = chain_up(start, lane);
+            in_insert = 1;
             changed_all(c, lane);                                      // :212
             if (aux != 0) { mark_subtree(at, lane); }                  // :213
             else { if (lane == 0) { relabel(at); } uniform_regs(); lds_fence(); }
+            in_insert = 0;
         }
         return ok;
     }
@@ -963,8 +1099,8 @@ __device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, 
     lut[lane + 192] = (uint16_t)lut_descend<T>(lnk, q3, bit, 8);
 }
 
-template <bool CODES> using LitTreeT = Tree<0, kLitLeaves, kLitNodes, 512, 0, 8, CODES>;
-template <bool CODES> using PosTreeT = Tree<kPosBase, kPosLeaves, kPosNodes, 32, kPosPos0, 6, CODES>;
+template <bool CODES, bool STATS> using LitTreeT = Tree<0, kLitLeaves, kLitNodes, 512, 0, 8, CODES, STATS>;
+template <bool CODES, bool STATS> using PosTreeT = Tree<kPosBase, kPosLeaves, kPosNodes, 32, kPosPos0, 6, CODES, STATS>;
 
 // ---------------------------------------------------------------------------------------------
 // Up to 64 tokens per step: lane = token (its lit-tree leaf `a`, then, for a back reference, its
@@ -977,6 +1113,7 @@ template <bool kWantCode, class LIT, class POS>
 __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, const LIT& lit, const POS& pos,
                                           int lane, int m, int a, int b,
                                           uint32_t& code_a, int& depth_a, uint32_t& code_b, int& depth_b) {
+    SEC_BEGIN
     const bool take = lane < m;
     const bool has_a = take && a >= 0, has_b = take && b >= 0;
     const int ia = has_a ? a : LIT::kRoot - 1, ib = has_b ? b : POS::kRoot - 1;      // (idle lanes look at a pad leaf)
@@ -1010,6 +1147,8 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
     auto probe = [&](int v, bool leaf, bool on) {
         Probe r;
         const uint32_t w = lds->rng[v];
+        const uint32_t pa = r_pa(w);
+        const uint32_t cv = lds->cnt[v], cp = lds->cnt[pa != kNil ? pa : (uint32_t)v];
         if (leaf) {
             r.st = r_pos(w); r.en = r.st + 1u;
         } else {
@@ -1017,17 +1156,18 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
             r.en = r_pos(lds->rng[r_last(w)]) + 1u;
         }
         r.n = on ? (uint32_t)lds->P8[r.en] - (uint32_t)lds->P8[r.st] : 0u;
-        const uint32_t pa = r_pa(w);
         r.tested = r.n != 0 && pa != kNil;
-        r.f = c_f(lds->cnt[v]);
-        r.fb = c_f(lds->cnt[r.tested ? pa : (uint32_t)v]);
+        r.f = c_f(cv);
+        r.fb = c_f(cp);
         return r;
     };
+    SEC(0)
     histogram(m);
+    SEC(1)
     // ---- every touched node's test: the tokens' own leaves (duplicates test the same node twice:
     //      harmless), then the internal nodes, one lane per node ------------------------------------
     constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
-    uint32_t nl[kLitRows], np = 0;
+    uint32_t nl[kLitRows], sel[kLitRows], np = 0, sep = 0;     // per row: chains through my node, its st | en << 16
     uint32_t bad = 0;                                   // bit 0 / 1: my leaves; bit 2 + r: my node of lit row r; bit 7: pos row
     {
         const Probe r = probe(ia, true, has_a);
@@ -1040,11 +1180,11 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
 #pragma unroll
     for (int row = 0; row < kLitRows; row++) {
         const int v = LIT::kRoot + row * kWave + lane;
-        nl[row] = 0;
+        nl[row] = 0; sel[row] = 0;
         if (LIT::kRoot + row * kWave < lit.next) {
             const bool on = v < lit.next && v != LIT::kRoot;
             const Probe r = probe(on ? v : LIT::kRoot, false, on);
-            nl[row] = r.n;
+            nl[row] = r.n; sel[row] = on ? (r.st | (r.en << 16)) : 0u;
             bad |= (r.tested && r.f + r.n > r.fb) ? (4u << row) : 0u;
         }
     }
@@ -1052,10 +1192,11 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         const int v = POS::kRoot + lane;
         const bool on = v < pos.next && v != POS::kRoot;
         const Probe r = probe(on ? v : POS::kRoot, false, on);
-        np = r.n;
+        np = r.n; sep = on ? (r.st | (r.en << 16)) : 0u;
         bad |= (r.tested && r.f + r.n > r.fb) ? 128u : 0u;
     }
     int ok = m;
+    SEC(2)
     if (__ballot(bad != 0) != 0) {
         // rare: some node would overtake its partner.  For each such node, the token that may not
         // pass is the (partner's count - its count + 1)-th one whose position lies below the node;
@@ -1079,18 +1220,16 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
                 if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
             }
         }
-        // count again for the prefix only
+        if (ok == 0) { return 0; }                              // nothing may be applied: the first token takes the exact path
+        // count again for the prefix only (the nodes' position runs are still in registers)
         histogram(ok);
 #pragma unroll
         for (int row = 0; row < kLitRows; row++) {
-            const int v = LIT::kRoot + row * kWave + lane;
-            const bool on = v < lit.next && v != LIT::kRoot;
-            nl[row] = probe(on ? v : LIT::kRoot, false, on).n;
+            nl[row] = (uint32_t)lds->P8[sel[row] >> 16] - (uint32_t)lds->P8[sel[row] & 0xFFFFu];
         }
-        const int v = POS::kRoot + lane;
-        const bool on = v < pos.next && v != POS::kRoot;
-        np = probe(on ? v : POS::kRoot, false, on).n;
+        np = (uint32_t)lds->P8[sep >> 16] - (uint32_t)lds->P8[sep & 0xFFFFu];
     }
+    SEC(3)
     // ---- apply the prefix: leaves one add per token (lanes holding the same symbol meet at its
     //      leaf); internal nodes one add per node, by the lane that tested it --------------------------
     if (lane < ok && has_a) { atomicAdd(&lds->cnt[ia], 1u); }
@@ -1098,10 +1237,11 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
 #pragma unroll
     for (int row = 0; row < kLitRows; row++) {
         const int v = LIT::kRoot + row * kWave + lane;
-        if (nl[row] != 0) { lds->cnt[v] += nl[row]; }
+        if (nl[row] != 0) { atomicAdd(&lds->cnt[v], nl[row]); }       // (one LDS instruction instead of read + write)
     }
-    if (np != 0) { lds->cnt[POS::kRoot + lane] += np; }
+    if (np != 0) { atomicAdd(&lds->cnt[POS::kRoot + lane], np); }
     lds_fence();
+    SEC(4)
     return ok;
 }
 

@@ -33,7 +33,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __shared__ static
-#define __launch_bounds__(n)
+#define __launch_bounds__(...)
 #define __restrict__ __restrict
 
 #define __ATOMIC_RELAXED_EMU 0
