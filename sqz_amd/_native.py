@@ -39,6 +39,21 @@ class BlockStats(C.Structure):
                [("lit_freq", C.c_uint32 * 288), ("pos_freq", C.c_uint32 * 32)]
 
 
+class RangeCoder(C.Structure):
+    """struct sqz_rc_range_coder of include/sqz/sqz_rc.h (struct range_coder, inc/sqz/sqz.h:45-53)."""
+
+
+RC_WRITE = C.CFUNCTYPE(None, C.POINTER(RangeCoder), C.c_uint8)
+RC_READ = C.CFUNCTYPE(C.c_uint8, C.POINTER(RangeCoder))
+RangeCoder._fields_ = [("low", C.c_uint64), ("range", C.c_uint64), ("code", C.c_uint64), ("write", RC_WRITE),
+                       ("read", RC_READ), ("error", C.c_int32), ("padding", C.c_int32)]
+
+
+class SqzRc(C.Structure):
+    """struct sqz_rc of include/sqz/sqz_rc.h (struct sqz at HEAD, inc/sqz/sqz.h:69-79)."""
+    _fields_ = [("rc", RangeCoder), ("that", C.c_void_p), ("reserved", C.c_uint64 * 8)]
+
+
 class Timing(C.Structure):
     """sqz_hip_timing: per-kernel summed durations (HIP events on the launch stream)."""
     _fields_ = [("ms", C.c_float * 8), ("launches", C.c_uint32 * 8)]
@@ -91,6 +106,12 @@ PROTOTYPES = {
     "sqz_hip_huffman_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "sqz_hip_debug_tree": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp]),
     "sqz_hip_pack_blocks": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
+    "sqz_rc_init": (None, [C.POINTER(SqzRc), _vp, C.c_size_t]),
+    "sqz_rc_compress": (None, [C.POINTER(SqzRc), _vp, C.c_size_t, C.c_uint32]),
+    "sqz_rc_decompress": (C.c_uint64, [C.POINTER(SqzRc), _vp, C.c_size_t]),
+    "sqz_rc_bound": (C.c_uint64, [C.c_uint64]),
+    "sqz_hip_rc_encode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sqz_hip_rc_decode_blocks": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sqz_hip_set_finder": (None, [C.c_int]),
     "sqz_hip_get_finder": (C.c_int, []),
     "sqz_hip_set_timing": (None, [C.c_int]),

@@ -56,6 +56,25 @@ class Encoder:
             _stream()), "sqz_hip_encode_blocks")
         return self.out, self.out_off, self.out_bytes, self.err
 
+    def encode_stats(self, d_in, in_off, window: int):
+        """encode + the reference's counters per block (sqz_block_stats):
+        returns (out, out_off, out_bytes, err, list of dicts)."""
+        st = torch.zeros(self.n * C.sizeof(N.BlockStats), dtype=torch.uint8, device=self.device)
+        _raise(N.lib().sqz_hip_encode_blocks_stats(
+            _ptr(d_in), _ptr(in_off), self.n, window, _ptr(self.out), _ptr(self.out_off),
+            _ptr(self.out_bytes), _ptr(self.err), _ptr(self.scratch), self.scratch_bytes, _ptr(st),
+            _stream()), "sqz_hip_encode_blocks_stats")
+        torch.cuda.synchronize()
+        raw = st.cpu().numpy().tobytes()
+        res = []
+        for b in range(self.n):
+            s = N.BlockStats.from_buffer_copy(raw, b * C.sizeof(N.BlockStats))
+            d = {k: int(getattr(s, k)) for k, _ in N.BlockStats._fields_[:12]}
+            d["lit_entropy"] = float(N.lib().sqz_stats_entropy(s.lit_freq, 288))
+            d["pos_entropy"] = float(N.lib().sqz_stats_entropy(s.pos_freq, 32))
+            res.append(d)
+        return self.out, self.out_off, self.out_bytes, self.err, res
+
     def tokens(self, d_in, in_off, window: int, finder: str = "index"):
         """stage 1 alone: (tokens int32[total], counts int32[n]).
 

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sqz_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "sqz_amd", "lib")
 LIB = os.path.join(LIBDIR, "libsqz_amd.so")
-SOURCES = ["abi.hip", "lz77_scan.hip", "lz77_index.hip", "huffman_emit.hip", "decode.hip", "zipf.hip", "blocks.hip"]
+SOURCES = ["abi.hip", "lz77_scan.hip", "lz77_index.hip", "huffman_emit.hip", "decode.hip", "zipf.hip", "blocks.hip", "range_coder.hip"]
 HEADERS = ["sqz_device.h", "sqz_tree.h", "sqz_kernels.h", "zipf_cdf.h"]
 PUBLIC = [os.path.join(ROOT, "include", "sqz", h) for h in ("sqz.h", "sqz_workload.h")]
 

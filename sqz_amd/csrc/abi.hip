@@ -5,6 +5,7 @@
 // flavour, kernel launches for the device flavour.  There is no CPU code path
 // for the codec itself: without a gfx950 device every call reports ENODEV.
 #include "../../include/sqz/sqz.h"
+#include "../../include/sqz/sqz_rc.h"
 #include "sqz_kernels.h"
 
 #include <errno.h>
@@ -814,6 +815,120 @@ int sqz_hip_pack_blocks(const void* d_slabs, const uint64_t* d_slab_off, const u
 
 void sqz_hip_set_finder(int finder) { g_finder.store(finder == 0 ? 0 : 1); }
 int  sqz_hip_get_finder(void) { return finder_default(); }
+
+// ------------------------------------------------------------------ R-era API (include/sqz/sqz_rc.h)
+uint64_t sqz_rc_bound(uint64_t bytes) { return 2 * bytes + 64; }
+
+void sqz_rc_init(struct sqz_rc* s, struct sqz_rc_map_entry entry[], size_t n) {       // src/sqz.c:550-565
+    (void)entry; (void)n;                     // HEAD disables its map inside sqz_compress (src/sqz.c:591)
+    if (s == NULL) { return; }
+    s->rc.low = 0;                            // rc_init :485-490 (write / read / that are the caller's)
+    s->rc.range = ~0ull;
+    s->rc.code = 0;
+    s->rc.error = 0;
+    memset(s->reserved, 0, sizeof(s->reserved));
+}
+
+int sqz_hip_rc_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, void* d_out,
+                             const uint64_t* d_out_off, uint64_t* d_out_bytes, int32_t* d_err, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL || d_out_bytes == NULL ||
+        d_err == NULL) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    sqzk::launch_rc_encode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, n,
+                           (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+int sqz_hip_rc_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, void* d_out,
+                             const uint64_t* d_out_off, uint64_t* d_out_bytes, uint64_t* d_consumed,
+                             int32_t* d_err, void* stream) {
+    if (n == 0) { return 0; }
+    if (d_in == NULL || d_in_off == NULL || d_out == NULL || d_out_off == NULL || d_out_bytes == NULL ||
+        d_err == NULL) { return EINVAL; }
+    const int e = device_ready();
+    if (e != 0) { return e; }
+    sqzk::launch_rc_decode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_out_bytes, d_consumed,
+                           d_err, n, (hipStream_t)stream);
+    return hip_errno(hipGetLastError());
+}
+
+// one stream through the device, host buffers; returns a HIP-side errno (0 = the kernel ran)
+static int rc_run_host(bool decode, const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_cap,
+                       uint64_t* produced, uint64_t* consumed, int32_t* err) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int e = probe_locked(c);
+    if (e != 0) { return e; }
+    if ((e = c.in.reserve(in_bytes + 16)) || (e = c.out.reserve(out_cap + 16)) || (e = c.in_off.reserve(16)) ||
+        (e = c.out_off.reserve(16)) || (e = c.out_bytes.reserve(16)) || (e = c.err.reserve(8))) { return e; }
+    hipStream_t st = nullptr;
+    const uint64_t io[2] = {0, in_bytes}, oo[2] = {0, out_cap};
+    if (in_bytes > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in, in_bytes, hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipMemcpyAsync(c.in_off.p, io, 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c.out_off.p, oo, 16, hipMemcpyHostToDevice, st));
+    uint64_t* d_sizes = (uint64_t*)c.out_bytes.p;               // [0] produced, [1] consumed
+    if (decode) {
+        sqzk::launch_rc_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
+                               (const uint64_t*)c.out_off.p, d_sizes, d_sizes + 1, (int32_t*)c.err.p, 1, st);
+    } else {
+        sqzk::launch_rc_encode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
+                               (const uint64_t*)c.out_off.p, d_sizes, (int32_t*)c.err.p, 1, st);
+    }
+    HIP_TRY(hipGetLastError());
+    uint64_t sizes[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(sizes, d_sizes, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(err, c.err.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t got = sizes[0] < out_cap ? sizes[0] : out_cap;
+    if (got > 0) { HIP_TRY(hipMemcpy(out, c.out.p, got, hipMemcpyDeviceToHost)); }
+    *produced = sizes[0];
+    if (consumed != NULL) { *consumed = decode ? sizes[1] : 0; }
+    return 0;
+}
+
+void sqz_rc_compress(struct sqz_rc* s, const void* d, size_t b, uint32_t window) {   // src/sqz.c:590-791
+    (void)window;                               // unused at HEAD but for an assert (:656)
+    if (s == NULL || s->rc.error != 0) { return; }
+    if ((b > 0 && d == NULL) || s->rc.write == NULL || b > kMaxStream) { s->rc.error = EINVAL; return; }
+    std::vector<uint8_t> buf(sqz_rc_bound(b));
+    uint64_t produced = 0;
+    int32_t err = 0;
+    const int e = rc_run_host(false, (const uint8_t*)d, b, buf.data(), buf.size(), &produced, NULL, &err);
+    if (e != 0) { s->rc.error = e; return; }
+    if (err != 0) { s->rc.error = err; return; }
+    for (uint64_t k = 0; k < produced && s->rc.error == 0; k++) { s->rc.write(&s->rc, buf[k]); }   // rc_emit :474-476
+}
+
+uint64_t sqz_rc_decompress(struct sqz_rc* s, void* data, size_t bytes) {               // src/sqz.c:793-839
+    if (s == NULL || s->rc.error != 0) { return 0; }
+    if ((bytes > 0 && data == NULL) || s->rc.read == NULL || bytes > kMaxStream) { s->rc.error = EINVAL; return 0; }
+    std::vector<uint8_t> in;
+    const uint64_t most = sqz_rc_bound(bytes) + 64;             // no stream of `bytes` literals is longer
+    uint64_t want = bytes / 2 + 16;
+    bool dry = false;
+    int src_error = 0;
+    for (;;) {
+        if (want > most) { want = most; }
+        while (in.size() < want && !dry) {                      // rc_consume :499-500, ahead of the decoder
+            const uint8_t v = s->rc.read(&s->rc);
+            if (s->rc.error != 0) { src_error = s->rc.error; s->rc.error = 0; dry = true; break; }
+            in.push_back(v);
+        }
+        uint64_t produced = 0, consumed = 0;
+        int32_t err = 0;
+        const int e = rc_run_host(true, in.data(), in.size(), (uint8_t*)data, bytes, &produced, &consumed, &err);
+        if (e != 0) { s->rc.error = e; return 0; }
+        if (consumed > in.size() && !dry && in.size() < most) { // ran past what was pulled: pull more, decode again
+            want = 2 * in.size() + 16;
+            continue;
+        }
+        if (consumed > in.size() && dry && src_error != 0) { err = src_error; }   // the source ended first: its error
+        s->rc.error = err;
+        return produced < bytes ? produced : bytes;
+    }
+}
 
 // ------------------------------------------------------------------ timing
 void sqz_hip_set_timing(int enabled) {

@@ -1,0 +1,308 @@
+// sqz_amd/csrc/range_coder.hip -- the reference's HEAD ("R-era") codec on gfx950 (SURVEY.md section
+// 8f-1): an adaptive order-0 range coder over byte models.  File:line = /root/reference/src/sqz.c.
+//
+//   struct prob_model + Fenwick tree  :398-472   -> RcModel: 256 counts in LDS, 4 per lane; a
+//                                                   cumulative count is a prefix sum over the lanes
+//                                                   (wave_scan), a lookup by cumulative count one
+//                                                   __ballot -- no tree of partial sums to keep
+//   rc_emit / rc_encode               :474-521   -> RcEncoder::put / encode
+//   rc_consume / rc_decode            :499-548   -> RcDecoder::consume / decode
+//   sqz_compress as HEAD runs it      :590-743   -> rc_encode_kernel: the finders are compiled out
+//                                                   (SURVEY.md section 0), every byte is a literal:
+//                                                   flag 1 + the byte, then flag 0 + size 0xFF, flush
+//   sqz_decompress                    :793-839   -> rc_decode_kernel, as written (back references included)
+//
+// One wavefront per independent stream, running uniformly: the coder's state (low, range, code) is a
+// serial chain of 64-bit divisions per symbol, so the parallelism is across streams and, inside
+// one, across the 256 counts of a model.  Throughput is bounded by that chain (about 500
+// instructions per byte); what the batch buys is thousands of streams at once.
+#include "sqz_device.h"
+#include "sqz_kernels.h"
+
+namespace sqzk {
+
+constexpr int kRcEINVAL = 22, kRcERANGE = 34, kRcEILSEQ = 84, kRcENOBUFS = 105;   // Linux errno values
+constexpr int kRcMinLen = 2, kRcMaxLen = 254;                                    // src/sqz.c:29-30
+
+struct RcLds {
+    uint32_t lit[256], size[256], byte[256], bits[256];      // struct prob_model x 4 (inc/sqz/sqz.h:73-76)
+    uint32_t dist[32][4];                                    // pm_dist[32], two symbols each (:77)
+};
+
+struct RcModel {
+    uint32_t* f;        // LDS: 256 counts (only the first n are ever non-zero)
+    uint32_t total;     // pm_total_freq (:451)
+
+    __device__ __forceinline__ void init(uint32_t* counts, uint32_t n, int lane) {     // pm_init :453-458
+        f = counts;
+        for (int k = lane; k < 256; k += kWave) { f[k] = (uint32_t)k < n ? 1u : 0u; }
+        total = n;
+    }
+    // start (counts below sym) and size of sym: pm_sum_of / freq (:447, :510)
+    __device__ __forceinline__ void span_of(uint32_t sym, int lane, uint32_t& start, uint32_t& size) const {
+        const uint4 v = reinterpret_cast<const uint4*>(f)[lane];
+        const uint32_t s = v.x + v.y + v.z + v.w;
+        const uint32_t excl = wave_scan(s) - s;
+        const uint32_t k = sym & 3u;
+        const uint32_t below = excl + (k > 0 ? v.x : 0u) + (k > 1 ? v.y : 0u) + (k > 2 ? v.z : 0u);
+        const uint32_t mine = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        start = (uint32_t)__builtin_amdgcn_readlane((int)below, (int)(sym >> 2));
+        size = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(sym >> 2));
+    }
+    // pm_index_of (:451, ft_index_of :432-445): the symbol whose run holds `sum`, with its span.  A sum
+    // at or past the total (a damaged stream) is symbol 0 there (ft_index_of's -1, plus 1), not an error.
+    __device__ __forceinline__ int find(uint64_t sum, int lane, uint32_t& start, uint32_t& size) const {
+        const uint4 v = reinterpret_cast<const uint4*>(f)[lane];
+        const uint32_t s = v.x + v.y + v.z + v.w;
+        const uint32_t excl = wave_scan(s) - s;
+        const uint32_t t = (uint32_t)sum;
+        const bool here = sum < (uint64_t)total && t >= excl && t < excl + s;
+        const uint64_t m = __ballot(here);
+        if (m == 0) {
+            start = 0;
+            size = (uint32_t)__builtin_amdgcn_readlane((int)v.x, 0);
+            return sum >= (uint64_t)total ? 0 : -1;
+        }
+        const int L = __builtin_ctzll(m);
+        const uint32_t c1 = excl + v.x, c2 = c1 + v.y, c3 = c2 + v.z;
+        const uint32_t k = t < c1 ? 0u : t < c2 ? 1u : t < c3 ? 2u : 3u;
+        const uint32_t below = k == 0 ? excl : k == 1 ? c1 : k == 2 ? c2 : c3;
+        const uint32_t mine = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        start = (uint32_t)__builtin_amdgcn_readlane((int)below, L);
+        size = (uint32_t)__builtin_amdgcn_readlane((int)mine, L);
+        return 4 * L + (int)(uint32_t)__builtin_amdgcn_readlane((int)k, L);
+    }
+    __device__ __forceinline__ void update(uint32_t sym, int lane) {                    // pm_update :466-472
+        // (the reference stops at a total of 2^56; a stream here is shorter than 2^31 symbols)
+        if (lane == 0) { f[sym] += 1u; }
+        total += 1u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        asm volatile("" ::: "memory");
+    }
+};
+
+struct RcEncoder {
+    uint64_t low, range;
+    uint8_t* out; uint64_t cap, written;
+    uint32_t pending; int n_pending;          // lane k holds pending byte k
+    int error;
+
+    __device__ __forceinline__ void put(int lane) {                                     // rc_emit :474-479
+        const uint32_t b = (uint32_t)(low >> 56);
+        if (lane == n_pending) { pending = b; }
+        n_pending++;
+        if (n_pending == kWave) { flush(lane); }
+        low <<= 8;
+        range <<= 8;
+    }
+    __device__ __forceinline__ void flush(int lane) {
+        if (lane < n_pending) {
+            if (written + (uint64_t)lane < cap) { out[written + (uint64_t)lane] = (uint8_t)pending; }
+        }
+        if (written + (uint64_t)n_pending > cap) { error = kRcENOBUFS; }
+        written += (uint64_t)n_pending;
+        n_pending = 0;
+    }
+    __device__ __forceinline__ bool same_top() const { return (low >> 56) == ((low + range) >> 56); }   // :481-483
+
+    __device__ __forceinline__ void encode(RcModel& m, uint32_t sym, int lane) {         // rc_encode :506-521
+        const uint64_t total = m.total;
+        uint32_t start, size;
+        m.span_of(sym, lane, start, size);
+        range /= total;
+        low += (uint64_t)start * range;
+        range *= (uint64_t)size;
+        m.update(sym, lane);
+        while (same_top()) { put(lane); }
+        if (range < total + 1) {
+            put(lane);
+            put(lane);
+            range = ~0ull - low;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kWave)
+void rc_encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
+                      uint64_t* __restrict__ out_bytes, int32_t* __restrict__ err_out, uint32_t n_blocks) {
+    __shared__ RcLds lds;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }
+    RcModel lit, size, byte;
+    lit.init(lds.lit, 2, lane); size.init(lds.size, 256, lane); byte.init(lds.byte, 256, lane);   // sqz_init :550-565
+    __syncthreads();
+    const uint8_t* src = in + uni64(in_off[b]);
+    const uint64_t bytes = uni64(in_off[b + 1]) - uni64(in_off[b]);
+    RcEncoder rc;
+    rc.low = 0; rc.range = ~0ull;                                                        // rc_init :485-490
+    rc.out = out + uni64(out_off[b]); rc.cap = uni64(out_off[b + 1]) - uni64(out_off[b]);
+    rc.written = 0; rc.pending = 0; rc.n_pending = 0; rc.error = 0;
+    for (uint64_t i0 = 0; i0 < bytes; i0 += kWave) {                                     // :614-739, as HEAD runs it
+        const uint32_t mine = i0 + (uint64_t)lane < bytes ? src[i0 + lane] : 0u;
+        const int n = bytes - i0 < (uint64_t)kWave ? (int)(bytes - i0) : kWave;
+        for (int k = 0; k < n; k++) {
+            rc.encode(lit, 1u, lane);                                                    // :722
+            rc.encode(byte, (uint32_t)__builtin_amdgcn_readlane((int)mine, k), lane);    // :723
+        }
+    }
+    rc.encode(lit, 0u, lane);                                                            // :741-742: end of stream
+    rc.encode(size, 0xFFu, lane);
+    for (int k = 0; k < 8; k++) { rc.range = ~0ull; rc.put(lane); }                      // rc_flush :492-497
+    rc.flush(lane);
+    if (lane == 0) { out_bytes[b] = rc.written; err_out[b] = rc.error; }
+}
+
+struct RcDecoder {
+    uint64_t low, range, code;
+    const uint8_t* in; uint64_t avail, consumed;
+    uint32_t row; uint64_t row_base;          // lane k holds in[row_base + k]
+    int error;
+
+    __device__ __forceinline__ uint32_t get(int lane) {      // rc.read: bytes past the end read as 0 (test.c:113-122)
+        if (consumed < row_base || consumed >= row_base + (uint64_t)kWave) {
+            row_base = consumed & ~(uint64_t)(kWave - 1);
+            row = row_base + (uint64_t)lane < avail ? in[row_base + lane] : 0u;
+        }
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)row, (int)(consumed - row_base));
+        consumed++;
+        return b;
+    }
+    __device__ __forceinline__ void consume(int lane) {                                  // rc_consume :499-504
+        code = (code << 8) + get(lane);
+        low <<= 8;
+        range <<= 8;
+    }
+    __device__ __forceinline__ bool same_top() const { return (low >> 56) == ((low + range) >> 56); }
+
+    __device__ __forceinline__ uint32_t decode(RcModel& m, int lane) {                    // rc_decode :528-548
+        const uint64_t total = m.total;
+        if (total < 1) { error = kRcEINVAL; return 0; }
+        if (range < total) {
+            consume(lane);
+            consume(lane);
+            range = ~0ull - low;
+        }
+        const uint64_t sum = (code - low) / (range / total);
+        uint32_t start, size;
+        const int sym = m.find(sum, lane, start, size);
+        if (sym < 0 || size == 0 || range < total) { error = kRcEILSEQ; return 0; }
+        range /= total;
+        low += (uint64_t)start * range;
+        range *= (uint64_t)size;
+        m.update((uint32_t)sym, lane);
+        while (same_top()) { consume(lane); }
+        return (uint32_t)sym;
+    }
+};
+
+__global__ __launch_bounds__(kWave)
+void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
+                      uint64_t* __restrict__ out_bytes, uint64_t* __restrict__ consumed_out,
+                      int32_t* __restrict__ err_out, uint32_t n_blocks) {
+    __shared__ RcLds lds;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }
+    RcModel lit, size, byte, bits;
+    lit.init(lds.lit, 2, lane); size.init(lds.size, 256, lane); byte.init(lds.byte, 256, lane); bits.init(lds.bits, 32, lane);
+    if (lane < 32) { lds.dist[lane][0] = 1; lds.dist[lane][1] = 1; lds.dist[lane][2] = 0; lds.dist[lane][3] = 0; }
+    __syncthreads();
+    uint8_t* d = out + uni64(out_off[b]);
+    const uint64_t cap = uni64(out_off[b + 1]) - uni64(out_off[b]);
+    RcDecoder rc;
+    rc.low = 0; rc.range = ~0ull; rc.code = 0; rc.error = 0;
+    rc.in = in + uni64(in_off[b]); rc.avail = uni64(in_off[b + 1]) - uni64(in_off[b]);
+    rc.consumed = 0; rc.row_base = ~0ull; rc.row = 0;
+    for (int k = 0; k < 8; k++) { rc.code = (rc.code << 8) + rc.get(lane); }             // :794-797
+    uint64_t i = 0;
+    uint32_t pend = 0; int n_pend = 0;                       // literals wait in lane k and leave 64 at a time
+    auto flush = [&]() {
+        if (lane < n_pend) { d[i - (uint64_t)n_pend + (uint64_t)lane] = (uint8_t)pend; }
+        n_pend = 0;
+    };
+    uint32_t dist_total[32];                                 // (only touched by streams with back references)
+#pragma unroll
+    for (int k = 0; k < 32; k++) { dist_total[k] = 2; }
+    while (rc.error == 0) {                                                              // :800-837
+        const uint32_t is_lit = rc.decode(lit, lane);
+        if (rc.error != 0) { break; }
+        if (is_lit != 0) {
+            if (i < cap) {
+                const uint32_t v = rc.decode(byte, lane);
+                if (lane == n_pend) { pend = v; }
+                n_pend++; i++;
+                if (n_pend == kWave) { flush(); }
+            } else { rc.error = kRcENOBUFS; }
+        } else {
+            const uint32_t sz = rc.decode(size, lane);
+            if (sz == 0xFFu) { break; }                                                  // end of stream :808
+            if (sz < (uint32_t)kRcMinLen || sz > (uint32_t)kRcMaxLen) { rc.error = kRcERANGE; }
+            else {
+                const uint32_t nb = rc.decode(bits, lane);
+                if (rc.error != 0) { break; }
+                uint32_t dd = 0;
+                for (int k = 0; k + 1 < (int)nb && rc.error == 0; k++) {                 // :817-819, one two-symbol model per bit
+                    RcModel m; m.f = lds.dist[k]; m.total = dist_total[k];
+                    // (a model is 256 counts wide for span/find: the dist models share the bits table's layout
+                    // only in their first four entries, so do the two-symbol arithmetic directly)
+                    const uint64_t total = m.total;
+                    if (rc.range < total) { rc.consume(lane); rc.consume(lane); rc.range = ~0ull - rc.low; }
+                    const uint64_t sum = (rc.code - rc.low) / (rc.range / total);
+                    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][0]);
+                    const uint32_t f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][1]);
+                    const uint32_t bit = (sum < f0 || sum >= total) ? 0u : 1u;      // (pm_index_of: past the total is symbol 0)
+                    const uint32_t start = bit ? f0 : 0u, sz2 = bit ? f1 : f0;
+                    if (rc.range < total) { rc.error = kRcEILSEQ; break; }
+                    rc.range /= total;
+                    rc.low += (uint64_t)start * rc.range;
+                    rc.range *= (uint64_t)sz2;
+                    if (lane == 0) { lds.dist[k][bit] += 1u; }
+                    dist_total[k] += 1u;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    while (rc.same_top()) { rc.consume(lane); }
+                    dd |= bit << k;
+                }
+                if (nb > 0) { dd |= nb < 32u ? (1u << nb) : 0u; }                         // :821
+                if (rc.error == 0) {
+                    const uint64_t n = i + sz;
+                    if (i < (uint64_t)dd) { rc.error = kRcERANGE; }
+                    else if (n <= cap) {                                                 // :826-830 byte-serial, overlap allowed
+                        flush();
+                        __threadfence_block();
+                        if (lane == 0) {
+                            for (uint64_t k = i; k < n; k++) {
+                                d[k] = __hip_atomic_load(d + k - dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __threadfence_block();
+                            }
+                        }
+                        __threadfence_block();
+                        i = n;
+                    } else { rc.error = kRcENOBUFS; }
+                }
+            }
+        }
+    }
+    flush();
+    if (lane == 0) {
+        out_bytes[b] = i;
+        err_out[b] = rc.error;
+        if (consumed_out != nullptr) { consumed_out[b] = rc.consumed; }
+    }
+}
+
+void launch_rc_encode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                      uint64_t* out_bytes, int32_t* err, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) { return; }
+    hipLaunchKernelGGL(rc_encode_kernel, dim3(n_blocks), dim3(kWave), 0, stream, in, in_off, out, out_off, out_bytes, err, n_blocks);
+}
+
+void launch_rc_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) { return; }
+    hipLaunchKernelGGL(rc_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream, in, in_off, out, out_off, out_bytes, consumed, err, n_blocks);
+}
+
+} // namespace sqzk

@@ -53,6 +53,14 @@ void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint
 void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,
                       const uint64_t* out_off, uint32_t n_blocks, hipStream_t stream);
 
+// the reference's HEAD range coder (range_coder.hip): literal-only encode as HEAD
+// runs it, decode as written.  Block b: in[in_off[b] .. in_off[b+1]) -> out + out_off[b], at most
+// out_off[b+1] - out_off[b] bytes; sizes to out_bytes[b], errno (EINVAL/EILSEQ/ERANGE/ENOBUFS) to err[b].
+void launch_rc_encode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                      uint64_t* out_bytes, int32_t* err, uint32_t n_blocks, hipStream_t stream);
+void launch_rc_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
+                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, hipStream_t stream);
+
 // slabs -> dense image of a batch's streams (blocks.hip): block b moves from src + src_off[b]
 // to dst + dst_off[b].  bytes[b] and all offsets are multiples of 8.
 void launch_compact_blocks(const uint8_t* src, const uint64_t* src_off, const uint64_t* bytes,

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("sqz.h", "sqz_workload.h"):
+    for h in ("sqz.h", "sqz_workload.h", "sqz_rc.h"):
         text = open(os.path.join(ROOT, "include", "sqz", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))

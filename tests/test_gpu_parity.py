@@ -493,3 +493,43 @@ def test_short_scratch_is_refused_per_block(sq, batch):
         a[bad] = None
         assert L.sqz_hip_encode_blocks(P(d_in), P(off), n, 1 << 12, a["d_out"], a["d_out_off"], a["d_out_bytes"],
                                        a["d_err"], P(enc.scratch), enc.scratch_bytes, None) == errno.EINVAL
+
+
+def test_reference_counters(sq, batch):
+    """the counters the reference keeps next to the hot path -- huffman.h:29-33
+    updates / swaps / moves per tree, the literal / back-reference byte split of squeeze.h:397-403,
+    huffman_entropy (huffman.h:237-249) and the depth marks -- returned per block by
+    sqz_hip_encode_blocks_stats and compared with what the COMPILED REFERENCE counted on the same
+    inputs (tests/golden/golden_r2.json), in one ragged batch per window."""
+    import torch
+    gold = G2["stats"]
+    for wb in (12, 15):
+        rows = [g for g in gold if g["win_bits"] == wb]
+        datas = []
+        for g in rows:
+            if g["name"].startswith("zipf"):
+                idx, nb = g["name"][4:].split("x")
+                datas.append(O.zipf_block(int(idx), int(nb)))
+            else:
+                datas.append(O.corpus(g["name"]))
+        n = len(datas)
+        off = np.concatenate([[0], np.cumsum([len(d) for d in datas])]).astype(np.int64)
+        d_in = torch.tensor(np.frombuffer(b"".join(datas), np.uint8).copy(), device="cuda")
+        enc = batch.Encoder(n, int(off[-1]), 0)
+        cap = [int(sq.bound(len(d))) for d in datas]
+        enc.out_off = torch.tensor(np.concatenate([[0], np.cumsum(cap)]).astype(np.int64), device="cuda")
+        enc.out = torch.empty(int(sum(cap)), dtype=torch.uint8, device="cuda")
+        out, out_off, out_bytes, err, stats = enc.encode_stats(d_in, torch.tensor(off, device="cuda"), 1 << wb)
+        assert err.tolist() == [0] * n
+        for g, st, data, nb in zip(rows, stats, datas, out_bytes.tolist()):
+            assert nb == g["out_bytes"], g["name"]
+            assert (st["lit_updates"], st["lit_swaps"], st["lit_moves"]) == (g["lit"]["updates"], g["lit"]["swaps"], g["lit"]["moves"]), g["name"]
+            assert (st["pos_updates"], st["pos_swaps"], st["pos_moves"]) == (g["pos"]["updates"], g["pos"]["swaps"], g["pos"]["moves"]), g["name"]
+            assert (st["literal_bytes"], st["backref_bytes"]) == (g["literal_bytes"], g["backref_bytes"]), g["name"]
+            assert st["literal_bytes"] + st["backref_bytes"] == len(data)
+            assert (st["lit_depth"], st["pos_depth"]) == (g["lit"]["depth"], g["pos"]["depth"]), g["name"]
+            assert abs(st["lit_entropy"] - g["lit"]["entropy"]) < 1e-12 and abs(st["pos_entropy"] - g["pos"]["entropy"]) < 1e-12
+            # and the stream is the one the default (counter-free) kernel writes
+            i = rows.index(g)
+            got = out[int(out_off[i]):int(out_off[i]) + nb].cpu().numpy().tobytes()
+            assert got == O.encode(data, wb, header=False)

@@ -184,3 +184,20 @@ def test_tree_invariants_the_kernels_rely_on():
         enc(bytes(rng.randrange(alpha) for _ in range(n)), rng.choice([32, 1 << 10]))
     enc(bytes(20000), 1 << 12)
     enc(b"abc" * 7000, 1 << 12)
+
+
+def test_restatement_under_sanitizers():
+    """the CPU restatement under ASan + UBSan over real inputs (encode, decode,
+    200 corrupted streams, the token-driven encoder with tight buffers, the tree alone): the golden
+    sizes / fingerprints must come out and the sanitizers must stay silent."""
+    import subprocess
+    subprocess.check_call(["make", "-C", O.ODIR, "-s", "asan-driver"])
+    exe = os.path.join(O.ODIR, "asan_driver")
+    gold = {(c["file"], c["win_bits"]): c for c in O.golden()["corpus"]}
+    for name, wb in (("laozi.txt", 10), ("laozi.txt", 15), ("confucius.txt", 12)):
+        c = gold[(name, wb)]
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+        p = subprocess.run([exe, os.path.join(O.CORPUS, name), str(wb), str(c["out_bytes"]), c["out_fnv"]],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0 and p.stdout.startswith("ok "), p.stdout + p.stderr
+        assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr
