@@ -212,7 +212,9 @@ __device__ __forceinline__ bool token_ok(uint32_t t) {
 // the longest prefix that changes no link, and the token it stops at (the tree really
 // restructures, or it needs the NYT escape) goes through the one-at-a-time path in the same step.
 template <bool kStats>                         // kStats: keep the reference's counters (sqz_block_stats)
-__global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
+// four waves per SIMD = 16 streams per CU, as many as the LDS allows; the counters build is a diagnostic
+// path and takes the registers it needs instead (bounded to 128 it spills 100 of them)
+__global__ __launch_bounds__(kWave, kStats ? 1 : 4)
 void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
                          const uint64_t* __restrict__ tok_off,
                          const uint32_t* __restrict__ tok_count,
@@ -390,14 +392,13 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     if (lane == 0) {
         out_bytes[b] = q.bytes;
         err_out[b] = err;
-        if (kStats && stats_out != nullptr) {
-            sqz_block_stats st;
-            st.lit_updates = lit.stats.updates; st.lit_swaps = lit.stats.swaps; st.lit_moves = lit.stats.moves;
-            st.pos_updates = pos.stats.updates; st.pos_swaps = pos.stats.swaps; st.pos_moves = pos.stats.moves;
-            st.literal_bytes = lit_tokens; st.backref_bytes = match_bytes;
-            st.lit_depth = (uint32_t)lit.depth; st.pos_depth = (uint32_t)pos.depth;
-            st.tokens = cursor; st.reserved = 0;
-            stats_out[b] = st;
+        if (kStats && stats_out != nullptr) {                     // (field by field: no 1.3 KB temporary on the stack)
+            sqz_block_stats* st = stats_out + b;
+            st->lit_updates = lit.stats.updates; st->lit_swaps = lit.stats.swaps; st->lit_moves = lit.stats.moves;
+            st->pos_updates = pos.stats.updates; st->pos_swaps = pos.stats.swaps; st->pos_moves = pos.stats.moves;
+            st->literal_bytes = lit_tokens; st->backref_bytes = match_bytes;
+            st->lit_depth = (uint32_t)lit.depth; st->pos_depth = (uint32_t)pos.depth;
+            st->tokens = cursor; st->reserved = 0;
         }
     }
     // leaf counts for huffman_entropy (huffman.h:237-249; the host does the logarithms)

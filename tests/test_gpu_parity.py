@@ -515,7 +515,7 @@ def test_reference_counters(sq, batch):
         n = len(datas)
         off = np.concatenate([[0], np.cumsum([len(d) for d in datas])]).astype(np.int64)
         d_in = torch.tensor(np.frombuffer(b"".join(datas), np.uint8).copy(), device="cuda")
-        enc = batch.Encoder(n, int(off[-1]), 0)
+        enc = batch.Encoder(n, int(off[-1]), 8)
         cap = [int(sq.bound(len(d))) for d in datas]
         enc.out_off = torch.tensor(np.concatenate([[0], np.cumsum(cap)]).astype(np.int64), device="cuda")
         enc.out = torch.empty(int(sum(cap)), dtype=torch.uint8, device="cuda")
