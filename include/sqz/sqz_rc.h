@@ -20,9 +20,10 @@
  * The coder itself runs on the device (sqz_amd/csrc/range_coder.hip).  The byte callbacks cannot
  * cross to it, so the shim serves them: compress runs to a host buffer and hands every byte to
  * rc.write in order (stopping at the first error the callback raises in rc.error); decompress pulls
- * bytes with rc.read ahead of the decoder -- first half the output size, then twice as much each
- * time the decoder ran past what was pulled -- so at most about twice the bytes the reference would
- * have asked for are read; rc.low / rc.range / rc.code are not meaningful after a call.
+ * bytes with rc.read ahead of the decoder -- 64 bytes, then twice as much each time the decoder ran
+ * past what was pulled (it starts over: the total work stays within twice the last attempt) -- so at
+ * most twice the bytes the reference would have asked for, plus 64, are read; rc.low / rc.range /
+ * rc.code are not meaningful after a call.
  * Errors are the reference's errno values in rc.error: EINVAL, EILSEQ (src/sqz.c:523-541), ERANGE,
  * ENOBUFS (:807-833), plus ENODEV (no gfx950 device: there is no CPU fallback) and ENOMEM.
  */

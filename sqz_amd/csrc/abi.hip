@@ -906,7 +906,7 @@ uint64_t sqz_rc_decompress(struct sqz_rc* s, void* data, size_t bytes) {        
     if ((bytes > 0 && data == NULL) || s->rc.read == NULL || bytes > kMaxStream) { s->rc.error = EINVAL; return 0; }
     std::vector<uint8_t> in;
     const uint64_t most = sqz_rc_bound(bytes) + 64;             // no stream of `bytes` literals is longer
-    uint64_t want = bytes / 2 + 16;
+    uint64_t want = 64;                                         // then twice as much each time the decoder ran dry
     bool dry = false;
     int src_error = 0;
     for (;;) {
@@ -921,7 +921,7 @@ uint64_t sqz_rc_decompress(struct sqz_rc* s, void* data, size_t bytes) {        
         const int e = rc_run_host(true, in.data(), in.size(), (uint8_t*)data, bytes, &produced, &consumed, &err);
         if (e != 0) { s->rc.error = e; return 0; }
         if (consumed > in.size() && !dry && in.size() < most) { // ran past what was pulled: pull more, decode again
-            want = 2 * in.size() + 16;
+            want = 2 * in.size();
             continue;
         }
         if (consumed > in.size() && dry && src_error != 0) { err = src_error; }   // the source ended first: its error
