@@ -94,7 +94,9 @@ def measured_traffic(kernel):
     if cur.get("kernel_build_id") != kernel_build_id():
         return None, (f"profiles/traffic.json was measured on build {cur.get('kernel_build_id')}, "
                       f"this is {kernel_build_id()}: not reported")
-    k = cur.get("kernels", {}).get(kernel)
+    ks = cur.get("kernels", {})
+    # rocprofv3 prints template instances as "void name<args>"
+    k = ks.get(kernel) or next((v for n, v in ks.items() if n.split("<")[0].split()[-1] == kernel), None)
     if not k:
         return None, "kernel not in profiles/traffic.json"
     return int(k["hbm_bytes_per_launch"]), cur.get("method")
@@ -310,7 +312,7 @@ def main():
             "config": {"workload": workload,
                        "total_blocks": total_blocks, "blocks_per_gpu": n, "block_bytes": bb, "win_bits": wb,
                        "parallelism": par,
-                       "finder": "index" if args.finder != "scan" else "scan",
+                       "finder": args.finder,
                        "device": info["name"]},
             "decode_MBps": round(in_total / dec_s * args.steps / 1e6, 3),
             "decode_ms_per_step": round(dec_s / args.steps * 1e3, 3),

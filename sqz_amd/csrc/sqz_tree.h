@@ -30,30 +30,36 @@
 // one-at-a-time path, so the output is always the reference's.
 //
 // n(v) WITHOUT WALKING ANY CHAIN.  Every leaf has a position in depth-first order (lo before
-// hi) and every node the interval [st, en) of the leaf positions below it.  With P = prefix sums
-// of the batch's histogram over positions, n(v) = P[en(v)] - P[st(v)] for ALL nodes at once:
-// one independent lookup per node (ten nodes per lane) instead of two dependent walks per
-// token with an LDS atomic on every level.  A node's test partner (sibling or uncle) is cached
-// next to its interval.  If node v fails its test, the first token that may not be applied is
-// the (f(partner) - f(v) + 1)-th one whose position lies in [st(v), en(v)); the earliest such
-// token over all failing nodes ends the batch.  tests/model/range_model.c is this algorithm in
-// plain C, held against the oracle's tree in lockstep (tests/test_range_model.py).
+// hi); the leaves below a node are the positions from its FIRST to its LAST leaf, and a node
+// remembers those two leaves (not the numbers: an insert shifts positions, leaf identities stay).
+// With P = inclusive prefix sums of the batch's histogram over positions,
+// n(v) = P[pos(last(v))] - P[pos(first(v)) - 1] for ALL nodes at once: independent lookups per
+// node (ten nodes per lane) instead of two dependent walks per token with an LDS atomic on every
+// level.  A node's test partner (sibling for a lo child, uncle for a hi child) is cached next to
+// its ends.  If node v fails its test, the first token that may not be applied is the
+// (f(partner) - f(v) + 1)-th one whose position lies below v; the earliest such token over all
+// failing nodes ends the batch.  tests/model/range_model.c is the first form of this algorithm
+// (numeric intervals) in plain C, held against the oracle's tree in lockstep
+// (tests/test_range_model.py); the kernels themselves run on the CPU in tests/emu.
 //
-// KEEPING THE INTERVALS.  A restructure (2 % of the symbols) moves whole subtrees; the exact
-// path does the reference's sequence and repairs intervals, depths, per-leaf codes and cached
-// partners with flat passes over the node arrays -- one lane per node, a few arithmetic
-// selects per node, no subtree walk:
-//     sibling exchange under p:  the two halves of [st(p), en(p)) trade places; one code bit flips
-//     promotion under g:         three neighbouring intervals rotate; one subtree comes up a level
+// KEEPING POSITIONS, ENDS AND PARTNERS.  A restructure (2 % of the symbols) moves whole subtrees;
+// the exact path does the reference's sequence and repairs positions, depths, per-leaf codes with
+// passes over the LEAVES only (one lane per leaf, a few selects), and ends / partners of the few
+// internal nodes on the climbed chain from registers (ballots + ds_bpermute):
+//     sibling exchange under p:  the two halves of p's leaf range trade places; one code bit flips
+//     promotion under g:         three neighbouring ranges rotate; one subtree comes up a level
 //                                (a code bit disappears), one goes down (a bit appears)
 //     insert:                    every position behind the split leaf moves one to the right
 //
 // Node words (LDS, 12 B per node):
 //     lnk  up | lo << 10 | hi << 20                    (10-bit absolute ids, 0x3FF = none)
-//     rng  st | en << 9 | partner << 18                (positions < 512; partner 0x3FF = untested)
-//     cnt  count (24 bits) | depth << 24 (6 bits)
+//     rng  leaf:     position (9 bits, 0x1FF = not in the tree)  | partner << 20
+//          internal: first leaf | last leaf << 10                | partner << 20   (0x3FF = untested)
+//     cnt  count (24 bits) | depth << 24 (6 bits; leaves only)     -- "aux" mode, trees < kAuxDepth
+//          count (32 bits), depths recomputed on demand            -- wide mode, for good once a
+//          tree reaches kAuxDepth or a stream kBatchTokens tokens (give_up_aux)
 // and for the encoder code[leaf slot]: the leaf's code in STREAM order (first branch = most
-// significant of `depth` bits), valid while the tree is shallower than kCodeDepth.
+// significant of `depth` bits), valid while the tree is shallower than kAuxDepth.
 #pragma once
 
 #include "sqz_device.h"
@@ -409,9 +415,6 @@ struct Tree {
         const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lu)) + 1u;
         const uint32_t xa = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fx));
         const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lx)) + 1u;
-#ifdef SQZ_DEBUG_TREE
-        if (lane == 0) { printf("promote g=%d dg=%u p=%d c=%d u=%d x=%u left=%d c[%u,%u) u[%u,%u) x[%u,%u)\n", g, dg, p, c, u, x, left, ca, cb, ua, ub, xa, xb); }
-#endif
         const int C = (int)(cb - ca), U = (int)(ub - ua), X = (int)(xb - xa);
         const int dc = left ? U : -(U + X), du = left ? -C : C + X, dx = left ? 0 : C - U;
         ga = left ? xa : ua;                                   // g's leaves: the three runs are neighbours

@@ -129,7 +129,8 @@ def test_tokens_vs_oracle(sq, batch, finder):
     blocks = [O.corpus("laozi.txt"), O.zipf_block(3, 20000), bytes(3000) + b"abc" * 700,
               O.corpus("confucius.txt")[:30000], b"", b"ab", b"abc", b"abcabc",
               bytes(rng.choice(b"ab") for _ in range(5000)), bytes(70000),
-              O.corpus("x64.elf")[4096:4096 + 50000]]
+              O.corpus("x64.elf")[4096:4096 + 50000], O.corpus("arm64.elf")[:40000],
+              bytes(rng.choice(b"abc") for _ in range(300)) * 120]
     sizes = [len(b) for b in blocks]
     off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device="cuda")
     d_in = torch.tensor(np.frombuffer(b"".join(blocks), np.uint8).copy(), device="cuda")
