@@ -21,6 +21,9 @@
 // child, a raw symbol that is out of range or already in the tree, a distance
 // reaching before the stream start and a match running past the stream end
 // are EINVAL; reading past the compressed bytes is E2BIG (bitstream.h:74).
+#define SQZ_CHANGED_INLINING __forceinline__
+#define SQZ_INSERT_INLINING __forceinline__
+#define SQZ_LUT_INLINING __forceinline__
 #include "sqz_tree.h"
 #include "sqz_kernels.h"
 

@@ -19,6 +19,8 @@
 // restructuring on the whole wave; its bits wait in a register and ride along with the next
 // batch's pack.
 #define SQZ_SEC_TIMERS            // (stats build: the section timers of sqz_tree.h report through this kernel)
+#define SQZ_CHANGED_INLINING __forceinline__
+#define SQZ_INSERT_INLINING __forceinline__
 #include "sqz_tree.h"
 #include "sqz_kernels.h"
 

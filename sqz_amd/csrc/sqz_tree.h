@@ -183,9 +183,18 @@ struct Chain {
 
 // The slow paths live in real (non-inlined) functions so that the per-step loop of the kernels
 // stays small (I-cache).  State crosses the call as plain values.
-template <class T> __device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
-template <class T> __device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane);
-template <class T> __device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane);
+#ifndef SQZ_INSERT_INLINING
+#define SQZ_INSERT_INLINING __noinline__
+#endif
+#ifndef SQZ_LUT_INLINING
+#define SQZ_LUT_INLINING __noinline__
+#endif
+template <class T> __device__ SQZ_INSERT_INLINING uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane);
+#ifndef SQZ_CHANGED_INLINING
+#define SQZ_CHANGED_INLINING __noinline__
+#endif
+template <class T> __device__ SQZ_CHANGED_INLINING uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane);
+template <class T> __device__ SQZ_LUT_INLINING void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane);
 
 // BASE: first node id; LEAVES / NODES: id space (leaves keep their symbol value + BASE, internal
 // nodes are numbered upwards from the root = BASE + LEAVES; the reference counts down from 2n-2, no
@@ -1025,7 +1034,7 @@ struct Tree {
 };
 
 template <class T>
-__device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane) {
+__device__ SQZ_INSERT_INLINING uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int lane) {
     T t;
     t.lds = lds; t.code = code; t.lut = nullptr; t.lut_ok = 0;
     t.stats.updates = t.stats.swaps = t.stats.moves = 0;
@@ -1036,7 +1045,7 @@ __device__ __noinline__ uint32_t slow_insert(TreeLds* lds, uint32_t* code, uint3
 }
 
 template <class T>
-__device__ __noinline__ uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane) {
+__device__ SQZ_CHANGED_INLINING uint32_t slow_changed(TreeLds* lds, uint32_t* code, uint32_t regs, int sym, int mine, int levels, int lane) {
     T t;
     t.lds = lds; t.code = code; t.lut = nullptr; t.lut_ok = 0;
     t.stats.updates = t.stats.swaps = t.stats.moves = 0;
@@ -1070,7 +1079,7 @@ __device__ __forceinline__ uint32_t lut_descend(const uint32_t* lnk, uint32_t pa
 }
 
 template <class T>
-__device__ __noinline__ void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane) {
+__device__ SQZ_LUT_INLINING void slow_build_lut(const uint32_t* lnk, uint16_t* lut, int lane) {
     // level by level from the root: the table for (L+1)-bit prefixes follows from the one
     // for L-bit prefixes with one link read per entry.  Lane j holds entry j while a level fits the wave.
     static_assert(T::kLutBits == 6 || T::kLutBits == 8, "table widths the decoder uses");
