@@ -350,12 +350,12 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                 }
             }
             if (deferred) { walk(resume); }
-            M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
+            M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : (key & 0xFFu);   // no match: the literal itself
             continue;
         }
         if (!valid) { continue; }
         walk(r);
-        M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : 0u;
+        M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : (key & 0xFFu);   // no match: the literal itself
     }
 }
 
@@ -372,9 +372,12 @@ constexpr int kChunk = 32;                          // positions per lane (<= 32
 constexpr int kTile = kChunk * kWave;               // positions per pass
 constexpr int kChunkRow = kChunk + 1;               // padded: same-offset reads of all lanes spread over the banks
 
+// 8,448 B per stream: 16 streams per CU, the whole 4096-block batch in one round (with the tile's
+// bytes staged as well it was 10,496 B, 15 per CU and two rounds: 9.9 ms instead of 5).  The
+// literal travels in the match word instead: len << 16 | dist for a match (len >= 3), the byte
+// itself (len field 0) where index_match_kernel found none.
 struct ParseLds {
-    uint32_t m[kChunkRow * kWave];                  // match word per position (0 = literal)
-    __attribute__((aligned(4))) uint8_t d[kTile];   // the bytes (literal tokens)
+    uint32_t m[kChunkRow * kWave];                  // match word per position
 };
 
 __device__ __forceinline__ uint32_t parse_slot(uint32_t k) { return k + (k / (uint32_t)kChunk); }
@@ -416,16 +419,7 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
         __syncthreads();
         for (uint32_t k = lane; k < have; k += kWave) {
             // positions bytes-2, bytes-1 have no 3-byte prefix: literal
-            lds.m[parse_slot(k)] = (tile + k + 2 < bytes) ? M[tile + k] : 0u;
-        }
-        for (uint32_t k = 4u * lane; k < have; k += 4u * kWave) {
-            uint32_t v = 0;
-            if (k + 4 <= have && ((reinterpret_cast<uintptr_t>(src + tile + k) & 3u) == 0)) {
-                v = *reinterpret_cast<const uint32_t*>(src + tile + k);
-            } else {
-                for (uint32_t j = 0; j < 4 && k + j < have; j++) { v |= (uint32_t)src[tile + k + j] << (8 * j); }
-            }
-            *reinterpret_cast<uint32_t*>(&lds.d[k]) = v;
+            lds.m[parse_slot(k)] = (tile + k + 2 < bytes) ? M[tile + k] : (uint32_t)src[tile + k];
         }
         __syncthreads();
 
@@ -479,7 +473,7 @@ void index_parse_kernel(const uint8_t* __restrict__ in,
             const uint32_t k = (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
             const uint32_t w = row[k];
-            tok[at++] = w != 0 ? (kTokMatch | w) : (uint32_t)lds.d[lo + k];
+            tok[at++] = (w >> 16) != 0 ? (kTokMatch | w) : (w & 0xFFu);
         }
         ntok += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
     }
