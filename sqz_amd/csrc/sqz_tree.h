@@ -1179,14 +1179,23 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
     // ---- every touched node's test: the tokens' own leaves (duplicates test the same node twice:
     //      harmless), then the internal nodes, one lane per node ------------------------------------
     constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
-    uint32_t nl[kLitRows], sel[kLitRows], np = 0, sep = 0;     // per row: chains through my node, its st | en << 16
+    // per tested node, kept in a register: its position run and how many chains may still pass it
+    // (st | en << 9 | min(partner's count - its count, 255) << 18)
+    auto pack = [](const Probe& r) {
+        const uint32_t allowed = r.fb > r.f ? r.fb - r.f : 0u;
+        return r.st | (r.en << 9) | ((allowed < 255u ? allowed : 255u) << 18);
+    };
+    uint32_t nl[kLitRows], sel[kLitRows], np = 0, sep = 0;     // per row: chains through my node, its packed test
     uint32_t bad = 0;                                   // bit 0 / 1: my leaves; bit 2 + r: my node of lit row r; bit 7: pos row
+    uint32_t sa, sb;
     {
         const Probe r = probe(ia, true, has_a);
+        sa = pack(r);
         bad |= (r.tested && r.f + r.n > r.fb) ? 1u : 0u;
     }
     {
         const Probe r = probe(ib, true, has_b);
+        sb = pack(r);
         bad |= (r.tested && r.f + r.n > r.fb) ? 2u : 0u;
     }
 #pragma unroll
@@ -1196,7 +1205,7 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         if (LIT::kRoot + row * kWave < lit.next) {
             const bool on = v < lit.next && v != LIT::kRoot;
             const Probe r = probe(on ? v : LIT::kRoot, false, on);
-            nl[row] = r.n; sel[row] = on ? (r.st | (r.en << 16)) : 0u;
+            nl[row] = r.n; sel[row] = on ? pack(r) : 0u;
             bad |= (r.tested && r.f + r.n > r.fb) ? (4u << row) : 0u;
         }
     }
@@ -1204,29 +1213,26 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         const int v = POS::kRoot + lane;
         const bool on = v < pos.next && v != POS::kRoot;
         const Probe r = probe(on ? v : POS::kRoot, false, on);
-        np = r.n; sep = on ? (r.st | (r.en << 16)) : 0u;
+        np = r.n; sep = on ? pack(r) : 0u;
         bad |= (r.tested && r.f + r.n > r.fb) ? 128u : 0u;
     }
     int ok = m;
     SEC(2)
     if (__ballot(bad != 0) != 0) {
-        // rare: some node would overtake its partner.  For each such node, the token that may not
-        // pass is the (partner's count - its count + 1)-th one whose position lies below the node;
-        // the earliest of them over all failing nodes ends the batch.
+        // some node would overtake its partner.  For each such node, the token that may not pass is
+        // the (partner's count - its count + 1)-th one whose position lies below the node; the
+        // earliest of them over all failing nodes ends the batch.  The failing lane's registers
+        // hold all that is needed.
 #pragma unroll
         for (int cat = 0; cat < 8; cat++) {
             uint64_t vm = __ballot((bad >> cat) & 1u);
+            const uint32_t mine = cat == 0 ? sa : cat == 1 ? sb : cat == 7 ? sep : sel[cat >= 2 && cat < 7 ? cat - 2 : 0];
             while (vm != 0) {
                 const int k = __builtin_ctzll(vm);
                 vm &= vm - 1;
-                int v;
-                if (cat == 0) { v = __builtin_amdgcn_readlane(ia, k); }
-                else if (cat == 1) { v = __builtin_amdgcn_readlane(ib, k); }
-                else if (cat == 7) { v = POS::kRoot + k; }
-                else { v = LIT::kRoot + (cat - 2) * kWave + k; }
-                const Probe r = probe(v, cat < 2, true);       // uniform: every lane looks at node v
-                const uint32_t allowed = r.fb > r.f ? r.fb - r.f : 0u;     // tokens through the node that may pass
-                const bool through = (has_a && qa >= r.st && qa < r.en) || (has_b && qb >= r.st && qb < r.en);
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+                const uint32_t st = t & 0x1FFu, en = (t >> 9) & 0x1FFu, allowed = t >> 18;
+                const bool through = (has_a && qa >= st && qa < en) || (has_b && qb >= st && qb < en);
                 const uint64_t tm = __ballot(through);
                 const uint64_t first_bad = __ballot(through && lanes_under(tm) == allowed);
                 if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
@@ -1237,9 +1243,9 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         histogram(ok);
 #pragma unroll
         for (int row = 0; row < kLitRows; row++) {
-            nl[row] = (uint32_t)lds->P8[sel[row] >> 16] - (uint32_t)lds->P8[sel[row] & 0xFFFFu];
+            nl[row] = (uint32_t)lds->P8[(sel[row] >> 9) & 0x1FFu] - (uint32_t)lds->P8[sel[row] & 0x1FFu];
         }
-        np = (uint32_t)lds->P8[sep >> 16] - (uint32_t)lds->P8[sep & 0xFFFFu];
+        np = (uint32_t)lds->P8[(sep >> 9) & 0x1FFu] - (uint32_t)lds->P8[sep & 0x1FFu];
     }
     SEC(3)
     // ---- apply the prefix: leaves one add per token (lanes holding the same symbol meet at its
