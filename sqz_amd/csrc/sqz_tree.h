@@ -80,11 +80,13 @@ constexpr int kCodeSlots = kPositions;        // code[]: lit leaf s -> s, pos le
 constexpr uint32_t kCountMask = (1u << 24) - 1u;
 constexpr int kDepthShift = 24;
 
-// Trees this deep leave the fast machinery for good (batches, interval passes, 32-bit codes):
+// Trees this deep leave the fast machinery for good (batches, position passes, 32-bit codes):
 // every symbol then takes the reference sequence on the chain held by the wave (depth < kMaxFastDepth)
-// or by one lane.  A chain of depth d needs counts that at least double per level (hi child <=
-// uncle, lo <= hi), i.e. 2^d symbols, so real streams stay far below either limit; the limits can
-// be lowered at build time so that tests reach the deep paths (tools/build_variants.sh).
+// or by one lane.  Depth grows by one per ~1.7 x more symbols at best (blocks of literals, each new
+// symbol 1.7 x as frequent as the last: 1.2e7 literals reach depth 27), so kAuxDepth is within reach
+// of long streams (tested in the shipping build) while kMaxFastDepth and kFreezeDepth are not under
+// 2^31 bytes; all three can be lowered at build time so that tests reach the deep paths
+// (python -m sqz_amd.build --variants).
 #ifndef SQZ_AUX_DEPTH
 #define SQZ_AUX_DEPTH 26
 #endif

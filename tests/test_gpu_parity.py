@@ -435,6 +435,48 @@ def test_caller_tokens_are_validated(sq, batch):
             assert err[b] == errno.EINVAL, (name, err[b])
 
 
+def deep_tree_literals(limit=1.2e7, ratio=1.7):
+    """literals in blocks, every new symbol about `ratio` times as frequent as the one before: the
+    shape that drives huffman.h's tree deep with the fewest symbols (ratio 2 gives depth = number
+    of symbols; Fibonacci weights only reach 16).  1.2e7 literals -> 30 symbols, depth 27."""
+    w = [1]
+    while sum(w) * ratio < limit:
+        w.append(max(int(round(w[-1] * ratio)), w[-1] + 1))
+    return np.repeat(np.arange(len(w), dtype=np.uint32), w)
+
+
+def test_deep_tree_in_the_shipping_build(sq, batch):
+    """The shipping build past its own thresholds: 11.7 M literals whose tree reaches depth 27
+    (>= 26: the trees leave the 24-bit count words, per-leaf codes and batches for the
+    one-at-a-time path with 32-bit counts, sqz_tree.h give_up_aux).  Stage 2 alone on the caller's
+    tokens against the oracle's stage 2 (the scan would find matches in such a text), then the
+    stream back through the decoder.  The lower-threshold variant builds (test_gpu_variants.py)
+    cover the one-lane path and the freeze, which need more than 2^31 symbols."""
+    import torch
+    from sqz_amd import _native as N
+    toks = deep_tree_literals()
+    e, want, st = O.encode_tokens(toks)
+    assert e == 0 and st.lit_depth >= 26, st.lit_depth
+    n_tok = len(toks)
+    off = torch.tensor([0, n_tok], dtype=torch.int64, device="cuda")
+    d_tok = torch.tensor(np.concatenate([toks, np.zeros(64, np.uint32)]).view(np.int32), device="cuda")
+    d_cnt = torch.tensor([n_tok], dtype=torch.int32, device="cuda")
+    cap = sq.bound(n_tok)
+    out_off = torch.tensor([0, cap], dtype=torch.int64, device="cuda")
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    out_bytes = torch.zeros(1, dtype=torch.int64, device="cuda")
+    err = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    rc = N.lib().sqz_hip_huffman_blocks(d_tok.data_ptr(), off.data_ptr(), d_cnt.data_ptr(), 1,
+                                        out.data_ptr(), out_off.data_ptr(), out_bytes.data_ptr(),
+                                        err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(err[0]) == 0
+    got = bytes(out[:int(out_bytes[0])].cpu().numpy())
+    assert len(got) == len(want) and got == want
+    back, derr = batch.decode_blocks_host([want], [n_tok])
+    assert derr[0] == 0 and back[0] == toks.astype(np.uint8).tobytes()
+
+
 def test_distance_32768_is_refused(sq, batch):
     """squeeze.h:534-541: 0 < pos <= 0x7FFF.  Distance code 29 with all 13 extra bits set is
     32768 -- encodable by the tables, refused by the reference's decoder (EINVAL).  A stream
