@@ -35,16 +35,35 @@ VARIANTS = {
 }
 
 
-def _build(name, unit):
+def _target(name, unit):
     out = os.path.join(EMU, f"libsqz_emu_{unit}_{name}.so")
     deps = [os.path.join(EMU, f) for f in ("emu_runtime.cpp", f"emu_{unit}.cpp", "hip/hip_runtime.h")] + \
            [os.path.join(CSRC, f) for f in ("sqz_tree.h", "sqz_device.h", "huffman_emit.hip", "decode.hip", "sqz_kernels.h")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", *VARIANTS[name], "-I" + EMU,
-                               "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-unused-variable",
-                               "-Wno-attributes", os.path.join(EMU, "emu_runtime.cpp"),
-                               os.path.join(EMU, f"emu_{unit}.cpp"), "-o", out])
-    return C.CDLL(out)
+    stale = not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", *VARIANTS[name], "-I" + EMU,
+           "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-unused-variable",
+           "-Wno-attributes", os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, f"emu_{unit}.cpp"), "-o", out]
+    return out, stale, cmd
+
+
+_all_built = False
+
+
+def _build(name, unit):
+    """the first call compiles every stale emulator library, all at once (eight g++ runs of ~30 s)"""
+    global _all_built
+    if not _all_built:
+        jobs = []
+        for v in VARIANTS:
+            for u in ("emit", "decode"):
+                out, stale, cmd = _target(v, u)
+                if stale:
+                    jobs.append((out, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        for out, p in jobs:
+            err = p.communicate()[1]
+            assert p.returncode == 0, f"{out}:\n{err[-3000:]}"
+        _all_built = True
+    return C.CDLL(_target(name, unit)[0])
 
 
 @pytest.fixture(scope="module", params=list(VARIANTS))
