@@ -28,6 +28,7 @@ reported in the same line (`decode_MBps`), together with
                 single-thread on a bounded sample of the same workload (rank 0, N=1)
 """
 import argparse
+import datetime
 import hashlib
 import json
 import os
@@ -141,7 +142,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SQZ_BENCH_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group(backend)
     # collectives run on device tensors over RCCL; a gloo rehearsal stages them through the host
@@ -219,55 +220,6 @@ def main():
     if not args.no_verify:
         assert torch.equal(d_back, d_in), "round trip differs"
 
-    # ---- N>1, strong: the same step with the batch starting and ending on rank 0 --------
-    xfer = None
-    if world > 1 and strong and not args.no_transfer:
-        root_in = batch.zipf_blocks(total_blocks, bb, first_block=0, device=dev) if rank == 0 else None
-        if root_in is not None and comm_dev.type == "cpu":
-            root_in = root_in.cpu()
-        dense_buf = torch.empty(n * (sqz_amd.bound(bb) // 8 * 8), dtype=torch.uint8, device=dev)
-        parts = {"scatter": 0.0, "encode": 0.0, "gather": 0.0}
-
-        def transfer_step(timed):
-            t_a = time.perf_counter()
-            mine, span = shard.scatter_blocks(root_in, total_blocks, bb, comm_dev)
-            mine = mine.to(dev)
-            torch.cuda.synchronize()
-            t_b = time.perf_counter()
-            o, o_off, o_bytes, e = enc.encode(mine, in_off, 1 << wb)
-            dense, d_off = batch.pack_blocks(o, o_off, o_bytes, dense=dense_buf)
-            torch.cuda.synchronize()
-            t_c = time.perf_counter()
-            res = shard.gather_dense(dense, o_bytes, total_blocks, comm_dev)
-            torch.cuda.synchronize()
-            t_d = time.perf_counter()
-            if timed:
-                parts["scatter"] += t_b - t_a
-                parts["encode"] += t_c - t_b
-                parts["gather"] += t_d - t_c
-            return res
-
-        for _ in range(args.warmup):
-            transfer_step(False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            root_dense, root_sizes, root_off = transfer_step(True)
-        barrier()
-        x_s = shard.max_over_ranks(time.perf_counter() - t0, comm_dev)
-        if rank == 0:
-            # what came back is the batch's streams in block order: rank 0's own range must
-            # equal what it encoded locally, and the sizes must add up to the job's total
-            own = root_dense[:int(root_off[n])].to(dev)
-            loc_dense, loc_off = batch.pack_blocks(out, out_off, out_bytes)
-            assert torch.equal(own, loc_dense[:own.numel()]), "gathered streams differ from the local encode"
-            xfer = {"encode_MBps": round(total_blocks * bb / x_s * args.steps / 1e6, 3),
-                    "ms_per_step": round(x_s / args.steps * 1e3, 3),
-                    "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
-                    "gathered_bytes": int(root_off[-1]),
-                    "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
-                            f"dense streams (point-to-point per peer) -> rank 0, backend {backend}"}
-
     if world > 1:
         enc_s = shard.max_over_ranks(enc_s, comm_dev)
         dec_s = shard.max_over_ranks(dec_s, comm_dev)
@@ -276,6 +228,59 @@ def main():
     else:
         comp_total = float(comp_bytes)
         tokens_all = tokens_rank
+
+    # ---- N>1, strong: the same step with the batch starting and ending on rank 0 --------
+    # (after every collective the device-local line needs: a failure here cannot take that line down)
+    xfer = None
+    if world > 1 and strong and not args.no_transfer:
+        try:
+            root_in = batch.zipf_blocks(total_blocks, bb, first_block=0, device=dev) if rank == 0 else None
+            if root_in is not None and comm_dev.type == "cpu":
+                root_in = root_in.cpu()
+            dense_buf = torch.empty(n * (sqz_amd.bound(bb) // 8 * 8), dtype=torch.uint8, device=dev)
+            parts = {"scatter": 0.0, "encode": 0.0, "gather": 0.0}
+
+            def transfer_step(timed):
+                t_a = time.perf_counter()
+                mine, span = shard.scatter_blocks(root_in, total_blocks, bb, comm_dev)
+                mine = mine.to(dev)
+                torch.cuda.synchronize()
+                t_b = time.perf_counter()
+                o, o_off, o_bytes, e = enc.encode(mine, in_off, 1 << wb)
+                dense, d_off = batch.pack_blocks(o, o_off, o_bytes, dense=dense_buf)
+                torch.cuda.synchronize()
+                t_c = time.perf_counter()
+                res = shard.gather_dense(dense, o_bytes, total_blocks, comm_dev)
+                torch.cuda.synchronize()
+                t_d = time.perf_counter()
+                if timed:
+                    parts["scatter"] += t_b - t_a
+                    parts["encode"] += t_c - t_b
+                    parts["gather"] += t_d - t_c
+                return res
+
+            for _ in range(args.warmup):
+                transfer_step(False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                root_dense, root_sizes, root_off = transfer_step(True)
+            barrier()
+            x_s = shard.max_over_ranks(time.perf_counter() - t0, comm_dev)
+            if rank == 0:
+                # what came back is the batch's streams in block order: rank 0's own range must
+                # equal what it encoded locally, and the sizes must add up to the job's total
+                own = root_dense[:int(root_off[n])].to(dev)
+                loc_dense, loc_off = batch.pack_blocks(out, out_off, out_bytes)
+                assert torch.equal(own, loc_dense[:own.numel()]), "gathered streams differ from the local encode"
+                xfer = {"encode_MBps": round(total_blocks * bb / x_s * args.steps / 1e6, 3),
+                        "ms_per_step": round(x_s / args.steps * 1e3, 3),
+                        "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
+                        "gathered_bytes": int(root_off[-1]),
+                        "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
+                                f"dense streams (point-to-point per peer) -> rank 0, backend {backend}"}
+        except Exception as ex:        # the device-local line above stands whatever the transfer leg does
+            xfer = {"error": f"{type(ex).__name__}: {ex}"[:400]}
 
     if rank == 0:
         in_total = float(total_blocks) * bb
