@@ -1,8 +1,11 @@
 /* tests/model/range_model.c -- TEST INFRASTRUCTURE ONLY.
  *
- * CPU model of the data structure the entropy kernels (sqz_amd/csrc/sqz_device.h) keep next to
- * the adaptive Huffman tree so that up to 64 tokens update it in one step WITHOUT walking any
- * leaf->root chain:
+ * CPU model of the arithmetic behind the entropy kernels' batched update (sqz_amd/csrc/sqz_tree.h,
+ * bump_batch): up to 64 tokens update the adaptive Huffman tree in one step WITHOUT walking any
+ * leaf->root chain.  This model keeps numeric intervals per node; the kernels keep, per node, its
+ * first and last LEAF and per leaf its position (the same intervals, cheaper to repair: only
+ * leaves are rewritten by a restructure) -- the tests n(v), the violation rule and the repairs
+ * per sibling exchange / promotion / insert are the ones modelled here:
  *
  *   every leaf has a position in depth-first order (lo before hi), every node the interval
  *   [st, en) of the leaf positions below it.  Then for a batch of symbols
@@ -12,7 +15,7 @@
  *   every node v the batch touches (parent p, sibling s, uncle u; f = counts before the batch):
  *       v is lo(p):                 f(v) + n(v) <= f(s)
  *       v is hi(p), p not the root: f(v) + n(v) <= f(u)
- *   (the proof is the comment above bump_lanes in sqz_device.h; the tests are the same, only
+ *   (the proof is in the head comment of sqz_tree.h; the tests are the same, only
  *   n(v) comes from the intervals instead of counters along the chains).  If some v fails, the
  *   first token that may not be applied is the (f(bound) - f(v) + 1)-th one through v; the
  *   tokens in front of the earliest such token are applied, the token itself takes the exact

@@ -1,5 +1,6 @@
-"""CPU: the interval ("range") form of the batched adaptive-Huffman update that the entropy
-kernels run (sqz_amd/csrc/sqz_device.h), restated in C with its flat per-node passes
+"""CPU: the interval ("range") form of the batched adaptive-Huffman update behind the entropy
+kernels (sqz_amd/csrc/sqz_tree.h keeps the same intervals as first/last leaf + leaf positions),
+restated in C with flat per-node passes
 (tests/model/range_model.c) and held against the oracle's tree in lockstep: same links,
 counts, depths, depth mark, codes and huffman.h:29-33 counters after every batch and after
 every exact step, on the reference's own tree fixtures, on the symbol streams of real
