@@ -37,17 +37,39 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build libsqz_amd.so")
 
 
-def build_native(force=False, verbose=True):
+def _lib_command(lib, flags=()):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + PUBLIC
-    if not force and not _stale(LIB, deps):
-        return LIB
+    return [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            "-fvisibility=hidden", *flags, "-I" + os.path.join(ROOT, "include"), "-o", lib] + srcs
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + PUBLIC
+
+
+def _run_all(cmds, verbose):
+    """the library builds are independent hipcc runs of ~80 s each: start them together"""
+    procs = []
+    for cmd in cmds:
+        if verbose:
+            print("[sqz_amd.build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+
+
+def build_native(force=False, verbose=True, variants=False):
+    """libsqz_amd.so (and, with variants=True, the lowered-threshold test builds) if stale"""
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-o", LIB] + srcs
-    if verbose:
-        print("[sqz_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    todo = []
+    if force or _stale(LIB, _deps()):
+        todo.append(_lib_command(LIB))
+    if variants:
+        for name, flags in VARIANTS.items():
+            if force or _stale(variant_path(name), _deps()):
+                todo.append(_lib_command(variant_path(name), flags))
+    _run_all(todo, verbose)
     return LIB
 
 
@@ -67,17 +89,7 @@ def variant_path(name):
 
 
 def build_variants(force=False, verbose=True):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + PUBLIC
-    for name, flags in VARIANTS.items():
-        lib = variant_path(name)
-        if not force and not _stale(lib, deps):
-            continue
-        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fvisibility=hidden", *flags, "-I" + os.path.join(ROOT, "include"), "-o", lib] + srcs
-        if verbose:
-            print("[sqz_amd.build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    build_native(force=force, verbose=verbose, variants=True)
 
 
 def build_oracle(verbose=True):
@@ -85,13 +97,11 @@ def build_oracle(verbose=True):
     odir = os.path.join(ROOT, "oracle")
     subprocess.check_call(["make", "-C", odir, "-s", "all", "freeze9"])
     if os.path.isdir("/root/reference/attic/map_experiment"):
-        subprocess.check_call(["make", "-C", odir, "-s", "ref"])
+        subprocess.check_call(["make", "-C", odir, "-s", "ref-all"])
     elif verbose:
         print("[sqz_amd.build] reference not mounted: oracle/_ref left as is", flush=True)
 
 
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv)
-    if "--variants" in sys.argv:
-        build_variants(force="--force" in sys.argv)
+    build_native(force="--force" in sys.argv, variants="--variants" in sys.argv)
     build_oracle()
