@@ -42,22 +42,29 @@ constexpr int kSortTile = 4 * kSortThreads;      // elements per workgroup tile 
 
 // The three digit histograms do not depend on the order of the elements (a position's key
 // bytes are fixed), so one sweep over the stream's BYTES gives all three; each pass is then a
-// single sweep over the elements (there used to be a counting sweep per pass as well: 24 GB of
-// element reads per batch instead of 12).  The scatter does
-// not write elements where they fall: every 4096-element tile is first ordered by digit in
-// LDS (stable: wave order, then row and lane order inside a wave), then copied out, so a
-// digit's elements of one tile leave as one contiguous run (16 elements = one line on
-// average, far longer for the frequent digits).  Writing each element straight to its
-// bucket kept ~256 half-filled lines open per wave -- 16 MB of open lines per XCD against
-// 4 MB of L2 -- and they left as partial-line writes: 53 GB written for 12 GB of elements.
+// single sweep over the elements.  The scatter does not write elements where they fall: every
+// 4096-element tile is first ordered by digit in LDS (stable: wave order, then row and lane order
+// inside a wave), then copied out, so a digit's elements of one tile leave as one contiguous run.
+// Writing each element straight to its bucket kept ~256 half-filled lines open per wave -- 16 MB
+// of open lines per XCD against 4 MB of L2 -- and they left as partial-line writes: 53 GB written
+// for 12 GB of elements.
+//
+// Which key bits a pass sorts by is free: all that is needed is that equal 24-bit keys end up
+// adjacent with positions ascending (a stable LSD sort over ANY split of the 24 bits).  Blocks of
+// up to 256 KB (positions < 2^18) use 10 + 7 + 7 bits: pass 0 reads the positions in order, so the
+// whole key is at hand, and the 14 bits it does not sort by travel in the element's top bits -- the
+// later passes never gather a byte at random (those gathers were half of the kernel's 28.8 GB of
+// fetches: 64 streams of 256 KB per XCD against 4 MB of L2).  Longer blocks use 8 + 8 + 8: pass 1
+// gathers bytes p and p+1 and carries byte 0 (blocks up to 16 MB), pass 2 of longer ones gathers.
+constexpr int kSortBins = 1024;                  // most digits of a pass
 struct SortLds {
-    uint32_t elem[kSortTile];            // the tile in digit order
-    uint8_t  dig[kSortTile];             // digit per tile slot
-    uint16_t cnt[kSortWaves][256];       // per tile: elements of (wave, digit) so far -> offset inside the digit's run
-    uint32_t gbase[3][256];              // per pass: where the next tile's run of digit d goes
-    uint32_t tstart[256];                // tile slot where digit d's run starts
-    uint32_t total[256];
-};
+    uint32_t elem[kSortTile];                    // the tile in digit order
+    uint16_t dig[kSortTile];                     // digit per tile slot
+    uint16_t cnt[kSortWaves][kSortBins];         // per tile: elements of (wave, digit) so far -> offset inside the digit's run
+    uint32_t gbase[3][kSortBins];                // per pass: where the next tile's run of digit d goes
+    uint32_t tstart[kSortBins];                  // tile slot where digit d's run starts
+    uint32_t total[kSortBins];
+};                                               // 76 KB: two workgroups per CU
 
 struct __attribute__((packed)) U32u { uint32_t v; };
 
@@ -65,14 +72,16 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     return reinterpret_cast<const U32u*>(p)->v;
 }
 
-// lanes of this wave with the same 8-bit digit (and valid), as a 64-bit mask
-__device__ __forceinline__ uint64_t peers_of(uint32_t digit, bool valid) {
+// lanes of this wave with the same digit (of `bits` bits) and valid, as a 64-bit mask
+__device__ __forceinline__ uint64_t peers_of(uint32_t digit, bool valid, int bits) {
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
-        const bool set = (digit >> bit) & 1u;
-        const uint64_t m = __ballot(set);
-        peers &= set ? m : ~m;
+    for (int bit = 0; bit < 10; bit++) {
+        if (bit < bits) {
+            const bool set = (digit >> bit) & 1u;
+            const uint64_t m = __ballot(set);
+            peers &= set ? m : ~m;
+        }
     }
     return peers;
 }
@@ -104,34 +113,44 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
     uint32_t* const pa = buf_a + in_off[b];
     uint32_t* const pb = buf_b + in_off[b];
     (void)tmp;                                                // (was the per-row byte cache of the counting sweeps)
-    // blocks up to 16 MB carry byte 0 of the key in the element's top 8 bits from
-    // pass 1 to pass 2, so only pass 1 gathers at random
-    const bool carry = bytes <= (1u << 24);
-    // ---- all three histograms from the bytes: pass p sorts by byte 2 - p of the key ---------
-    for (int d = tid; d < 3 * 256; d += kSortThreads) { (&lds.gbase[0][0])[d] = 0; }
+    // the key of position k as one number: byte k first (most significant), byte k+2 last
+    auto key_of = [&](uint32_t k) {
+        return (uint64_t)k + 4 <= bytes ? (__builtin_bswap32(load_u32_unaligned(src + k)) >> 8)
+                                        : (((uint32_t)src[k] << 16) | ((uint32_t)src[k + 1] << 8) | (uint32_t)src[k + 2]);
+    };
+    const bool small = bytes <= (1u << 18);                   // the unsorted key bits fit above the position
+    const bool carry = bytes <= (1u << 24);                   // (8 + 8 + 8) byte 0 fits above the position
+    // pass p sorts by key bits [shift[p], shift[p] + width[p])
+    const int w0 = small ? 10 : 8, w1 = small ? 7 : 8, w2 = small ? 7 : 8;
+    const int s1 = w0, s2 = w0 + w1;
+    const uint32_t m0 = (1u << w0) - 1u, m1 = (1u << w1) - 1u;
+    // ---- all three histograms from the bytes ------------------------------------------------
+    for (int d = tid; d < 3 * kSortBins; d += kSortThreads) { (&lds.gbase[0][0])[d] = 0; }
     __syncthreads();
     for (uint32_t k = (uint32_t)tid; k < count; k += (uint32_t)kSortThreads) {
-        atomicAdd(&lds.gbase[0][src[k + 2]], 1u);
-        atomicAdd(&lds.gbase[1][src[k + 1]], 1u);
-        atomicAdd(&lds.gbase[2][src[k]], 1u);
+        const uint32_t key = key_of(k);
+        atomicAdd(&lds.gbase[0][key & m0], 1u);
+        atomicAdd(&lds.gbase[1][(key >> s1) & m1], 1u);
+        atomicAdd(&lds.gbase[2][key >> s2], 1u);
     }
     __syncthreads();
     if (wave < 3) {                                        // exclusive scans: counts -> bases
         uint32_t* const g = lds.gbase[wave];
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = g[4 * lane + j]; sum += v[j]; }
+        const int per = (1 << (wave == 0 ? w0 : wave == 1 ? w1 : w2)) / kWave;     // 16, 4 or 2 digits per lane
+        uint32_t sum = 0;
+        for (int j = 0; j < per; j++) { sum += g[per * lane + j]; }
         uint32_t excl = wave_scan(sum) - sum;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { g[4 * lane + j] = excl; excl += v[j]; }
+        for (int j = 0; j < per; j++) { const uint32_t v = g[per * lane + j]; g[per * lane + j] = excl; excl += v; }
     }
     __syncthreads();
 
     for (int pass = 0; pass < 3; pass++) {
-        // pass 0: identity -> A by byte 2 ; pass 1: A -> B by byte 1 ; pass 2: B -> A by byte 0
+        // pass 0: identity -> A ; pass 1: A -> B ; pass 2: B -> A
         const uint32_t* from = pass == 1 ? pa : pb;
         uint32_t* to = pass == 1 ? pb : pa;
         uint32_t* const gbase = lds.gbase[pass];
+        const int bits = pass == 0 ? w0 : pass == 1 ? w1 : w2;
+        const int bins = 1 << bits;
 
         // element k of the input order belongs to tile k / 4096, wave (k / 256) % 16, row (k / 64) % 4
         auto load_rows = [&](uint32_t tile, uint32_t (&elem)[4], uint32_t (&digit)[4], bool (&valid)[4]) {
@@ -145,16 +164,27 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 digit[j] = 0; elem[j] = pos[j];
-                if (valid[j]) {
-                    if (pass == 0) { digit[j] = src[pos[j] + 2]; }
-                    else if (pass == 1) {          // the one random gather: bytes p and p+1
-                        const uint32_t w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
-                        digit[j] = w >> 8;
-                        if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
+                if (!valid[j]) { continue; }
+                if (small) {
+                    if (pass == 0) {
+                        const uint32_t key = key_of(pos[j]);
+                        digit[j] = key & m0;
+                        elem[j] = pos[j] | ((key >> 10) << 18);          // 14 key bits above an 18-bit position
+                    } else if (pass == 1) {
+                        digit[j] = (pos[j] >> 18) & m1;
                     } else {
-                        digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
-                        if (carry) { elem[j] = pos[j] & 0x00FFFFFFu; }
+                        digit[j] = pos[j] >> 25;
+                        elem[j] = pos[j] & 0x3FFFFu;
                     }
+                } else if (pass == 0) {
+                    digit[j] = src[pos[j] + 2];
+                } else if (pass == 1) {                              // the one random gather: bytes p and p+1
+                    const uint32_t w = (uint32_t)src[pos[j]] | ((uint32_t)src[pos[j] + 1] << 8);
+                    digit[j] = w >> 8;
+                    if (carry) { elem[j] = pos[j] | ((w & 0xFFu) << 24); }
+                } else {
+                    digit[j] = carry ? (pos[j] >> 24) : (uint32_t)src[pos[j]];
+                    if (carry) { elem[j] = pos[j] & 0x00FFFFFFu; }
                 }
             }
         };
@@ -162,13 +192,13 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
         // ---- scatter, tile by tile ------------------------------------------------------
         for (uint32_t tile = 0; tile < count; tile += (uint32_t)kSortTile) {
             const uint32_t n_tile = count - tile < (uint32_t)kSortTile ? count - tile : (uint32_t)kSortTile;
-            for (int d = lane; d < 256; d += kWave) { lds.cnt[wave][d] = 0; }
+            for (int d = lane; d < bins; d += kWave) { lds.cnt[wave][d] = 0; }
             uint32_t elem[4], digit[4], wrank[4];
             bool valid[4];
             load_rows(tile, elem, digit, valid);
 #pragma unroll
             for (int j = 0; j < 4; j++) {                      // rows in order: stability
-                const uint64_t peers = peers_of(digit[j], valid[j]);
+                const uint64_t peers = peers_of(digit[j], valid[j], bits);
                 const uint32_t rank = lanes_below(peers);
                 wrank[j] = valid[j] ? (uint32_t)lds.cnt[wave][digit[j]] + rank : 0u;
                 __builtin_amdgcn_wave_barrier();               // all reads before the leaders' writes
@@ -179,7 +209,7 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
             }
             __syncthreads();
             uint32_t tcount = 0;
-            if (tid < 256) {                                   // offsets of the waves inside a digit's run
+            if (tid < bins) {                                  // offsets of the waves inside a digit's run
                 for (int w = 0; w < kSortWaves; w++) {
                     const uint32_t c = lds.cnt[w][tid];
                     lds.cnt[w][tid] = (uint16_t)tcount;
@@ -189,14 +219,11 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
             }
             __syncthreads();
             if (wave == 0) {                                   // where each digit's run starts in the tile
-                uint32_t v[4], s = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[j] = lds.total[4 * lane + j]; s += v[j]; }
-                uint32_t incl = s;
-                incl = wave_scan(incl);
-                uint32_t excl = incl - s;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { lds.tstart[4 * lane + j] = excl; excl += v[j]; }
+                const int per = bins / kWave;
+                uint32_t sum = 0;
+                for (int j = 0; j < per; j++) { sum += lds.total[per * lane + j]; }
+                uint32_t excl = wave_scan(sum) - sum;
+                for (int j = 0; j < per; j++) { lds.tstart[per * lane + j] = excl; excl += lds.total[per * lane + j]; }
             }
             __syncthreads();
 #pragma unroll
@@ -205,7 +232,7 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
                     const uint32_t slot = lds.tstart[digit[j]] + (uint32_t)lds.cnt[wave][digit[j]] + wrank[j];
                     if (slot < (uint32_t)kSortTile) {          // always: slots are a permutation of [0, n_tile)
                         lds.elem[slot] = elem[j];
-                        lds.dig[slot] = (uint8_t)digit[j];
+                        lds.dig[slot] = (uint16_t)digit[j];
                     }
                 }
             }
@@ -220,7 +247,7 @@ void index_sort_kernel(const uint8_t* __restrict__ in,
                 }
             }
             __syncthreads();
-            if (tid < 256) { gbase[tid] += tcount; }
+            if (tid < bins) { gbase[tid] += tcount; }
         }
         // the next pass reads what other waves of this workgroup wrote
         __threadfence_block();
