@@ -208,6 +208,10 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     // CU within a quarter of each other and shortens the tail.
     const uint64_t quarter = (bytes >> 2) + 1;
     int prio_now = -1;
+    // tokens read ahead in the previous step that its exact update left valid (below): they open this
+    // step's batch without being decoded again
+    int kept = 0;
+    uint32_t kept_bits = 0, kept_slot = 0;
     while (i < bytes && err == 0) {
         {
             const int q = (int)(i / quarter);                  // 0..3
@@ -231,8 +235,10 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         //      start at ITS bit offset, then the real starts are picked by following the
         //      lengths from the known start (64 offsets per round, up to 64 tokens) ----------
         const uint64_t bit0 = r.pos;
-        uint64_t base = bit0;
-        int m = 0;
+        uint64_t base = bit0 + kept_bits;
+        int m = frozen ? 0 : kept;
+        if (lane < m) { slot[lane] = kept_slot; }
+        kept = 0; kept_bits = 0;
         bool stop = frozen;
         while (m < want && !stop) {
             const uint32_t k0 = (uint32_t)(base >> 5);
@@ -341,8 +347,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         ST_SEC(1)
         lds_fence();
         // ---- lane j = token j: positions, validity, symbols ---------------------------------
-        uint32_t word_v = 0, used_v = 0;
-        if (lane < m) { const uint32_t sl = slot[lane]; word_v = sl & 0x81FFFFFFu; used_v = ((sl >> 25) & 63u) + 1u; }
+        uint32_t word_v = 0, used_v = 0, slot_v = 0;
+        if (lane < m) { slot_v = slot[lane]; word_v = slot_v & 0x81FFFFFFu; used_v = ((slot_v >> 25) & 63u) + 1u; }
         const bool is_match = (word_v & kTokMatch) != 0;
         const uint32_t tlen_v = lane < m ? (is_match ? ((word_v >> 16) & 0x1FFu) : 1u) : 0u;
         uint32_t scan = (used_v << 16) | tlen_v;               // both sums fit 16 bits
@@ -388,7 +394,41 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         st_hist[done == 0 ? 0 : done < 8 ? 1 : done < 24 ? 2 : done < 64 ? 3 : 4]++;
 #endif
         ST_SEC(4)
-        if (i < bytes && (stop || done < m)) { decode_one(); }
+        if (i < bytes && (stop || done < m)) {
+            const bool may_keep = done + 1 < m;              // the step ended on a token the batch refused: the
+            if (may_keep && lane == 0) {                     // ones behind it were decoded with the tree as it was
+                lds.tree.pend[LitTree::kChgSlot] = 0x7FFFFFFFu; lds.tree.pend[LitTree::kChgSlot + 1] = 0u;
+                lds.tree.pend[PosTree::kChgSlot] = 0x7FFFFFFFu; lds.tree.pend[PosTree::kChgSlot + 1] = 0u;
+            }
+            lds_fence();
+            decode_one();
+            lds_fence();
+            const bool still = (lit.complete | pos.complete) == 0 && lit.depth < kFreezeDepth && pos.depth < kFreezeDepth &&
+                               (lit.aux & pos.aux) != 0;
+            if (may_keep && still && err == 0 && i < bytes) {
+                // A token behind the exact one is still right if neither of its leaves got a new code: the
+                // same bits then lead to the same leaf in the new tree.  Keep the run of such tokens.
+                const uint32_t la = lds.tree.pend[LitTree::kChgSlot], ha = lds.tree.pend[LitTree::kChgSlot + 1];
+                const uint32_t lb = lds.tree.pend[PosTree::kChgSlot], hb = lds.tree.pend[PosTree::kChgSlot + 1];
+                const bool cand = lane > done && lane < m;
+                bool moved = false;
+                if (cand) {
+                    const uint32_t qa = r_pos(lds.tree.rng[a_v]);
+                    moved = qa >= la && qa < ha;
+                    if (is_match) { const uint32_t qb = r_pos(lds.tree.rng[b_v]); moved |= qb >= lb && qb < hb; }
+                }
+                const uint64_t behind = ~0ull << (done + 1);
+                const uint64_t ends = (__ballot(!cand || moved) & behind);      // lanes >= m are not candidates: never empty
+                const int first_out = ends != 0 ? __builtin_ctzll(ends) : kWave;
+                kept = first_out - (done + 1);
+                if (kept > 0) {
+                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)scan, done) >> 16;
+                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)scan, done + kept) >> 16;
+                    kept_bits = s1 - s0;
+                    kept_slot = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + done + 1) & (kWave - 1)) << 2, (int)slot_v);
+                }
+            }
+        }
         ST_SEC(5)
         {   // a step that ran short is usually followed by more short ones (the tree is still moving)
             avg4 += done - (avg4 >> 2);

@@ -222,6 +222,7 @@ struct Tree {
     static constexpr int kRoot = BASE + LEAVES;
     static constexpr int kLeaves = LEAVES;
     static constexpr int kLutBits = LUT_BITS;
+    static constexpr int kChgSlot = BASE == 0 ? 57 : 59;   // pend[]: positions whose codes an exact step changed (decoder)
     static constexpr int kIdEnd = BASE + ((LEAVES + 1 + REF_LEAVES - 2) < NODES ? (LEAVES + 1 + REF_LEAVES - 2) : NODES);
     static constexpr bool kCodes = CODES;
     static constexpr int kLeafRows = (LEAVES + kWave - 1) / kWave;
@@ -294,6 +295,15 @@ struct Tree {
     // the root, then the deepest node of top's subtree -- always a leaf, one of those at positions
     // [a, b).  The walk visits every node of the subtree once (huffman.h:42): 2 * leaves - 1 of them.
     __device__ __forceinline__ void mark_range(int top, uint32_t a, uint32_t b, uint32_t deepest_known, int lane) {
+        // Every restructure comes through here with the positions [a, b) of the leaves below the node
+        // whose paths the reference recomputes (huffman_update_paths): those and only those leaves may
+        // have a new code.  The decoder keeps the union per exact step (pend[kChgSlot], [kChgSlot + 1];
+        // nothing is pending at that level in a tree this shallow): tokens it has read ahead whose
+        // leaves lie outside it are still what the new tree decodes at their bit offsets.
+        if (!CODES && lane == 0) {
+            atomicMin(&lds->pend[kChgSlot], a);
+            atomicMax(&lds->pend[kChgSlot + 1], b);
+        }
         uint32_t deepest = deepest_known;
         // At rest the mark is at least the depth of every node (a walk from the root sets it to the true
         // maximum, every later walk raises it to what it saw): a walk over unchanged depths cannot move it,

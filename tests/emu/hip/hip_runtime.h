@@ -156,6 +156,8 @@ inline uint32_t __brev(uint32_t v) {
     return __builtin_bswap32(v);
 }
 template <class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = (T)(o + v); return o; }
+template <class T> inline T atomicMin(T* p, T v) { const T o = *p; *p = v < o ? v : o; return o; }
+template <class T> inline T atomicMax(T* p, T v) { const T o = *p; *p = v > o ? v : o; return o; }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define HIP_SYMBOL(x) x
