@@ -384,7 +384,6 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
             i += (uint64_t)(af & 0xFFFFu);
             resume = bit0 + (uint64_t)(af >> 16);
         }
-        r.seek(resume);
         // ---- whatever stopped the step: one token, exactly ------------------------------------
 #ifdef SQZ_STATS
         st_steps++; st_m += (uint32_t)m; st_done += (uint32_t)done;
@@ -401,7 +400,26 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                 lds.tree.pend[PosTree::kChgSlot] = 0x7FFFFFFFu; lds.tree.pend[PosTree::kChgSlot + 1] = 0u;
             }
             lds_fence();
-            decode_one();
+            if (done < m) {
+                // the token the batch refused sits in lane `done`, read ahead and checked like the others:
+                // only its updates are left to do, one symbol at a time (squeeze.h:509-549 without the reads)
+                const int sa = __builtin_amdgcn_readlane(a_v, done), sb = __builtin_amdgcn_readlane(b_v, done);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)word_v, done);
+                const uint32_t u1 = (uint32_t)__builtin_amdgcn_readlane((int)used_v, done);
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)tlen_v, done);
+                { const Chain c = lit.chain_up(sa, lane); (void)lit.bump_wave(sa, c, lane); }
+                if (sb >= 0) { const Chain c = pos.chain_up(sb, lane); (void)pos.bump_wave(sb, c, lane); }
+                if (lit.fault | pos.fault) { err = kE2BIG; }
+                else {
+                    if (lane == 0) { tok[ntok] = w1; }
+                    ntok++;
+                    i += (uint64_t)l1;
+                    r.seek(resume + (uint64_t)u1);
+                }
+            } else {
+                r.seek(resume);
+                decode_one();
+            }
             lds_fence();
             const bool still = (lit.complete | pos.complete) == 0 && lit.depth < kFreezeDepth && pos.depth < kFreezeDepth &&
                                (lit.aux & pos.aux) != 0;
@@ -428,6 +446,8 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
                     kept_slot = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + done + 1) & (kWave - 1)) << 2, (int)slot_v);
                 }
             }
+        } else {
+            r.seek(resume);
         }
         ST_SEC(5)
         {   // a step that ran short is usually followed by more short ones (the tree is still moving)
