@@ -348,6 +348,25 @@ def test_corrupt_streams_do_not_fault(sq, batch):
             assert got == out
 
 
+@pytest.mark.parametrize("n_bytes", [(1 << 18) - 1, 1 << 18, (1 << 18) + 1, 300000])
+def test_sort_key_split_boundary(sq, batch, n_bytes):
+    """index_sort_kernel sorts blocks of up to 2^18 bytes by 10 + 7 + 7 key bits with the rest of the
+    key carried in the element, longer ones by 8 + 8 + 8 with a gather (lz77_index.hip): both sides of
+    the boundary, token for token against the oracle (window 2^10 keeps it in seconds) and the scan."""
+    import torch
+    window = 1 << 10
+    data = O.zipf_block(5, n_bytes)
+    d_in = torch.tensor(np.frombuffer(data, np.uint8).copy(), device="cuda")
+    off = torch.tensor([0, n_bytes], dtype=torch.int64, device="cuda")
+    enc = batch.Encoder(1, n_bytes, sq.bound(n_bytes))
+    want = O.tokens(data, window)
+    for finder in ("index", "scan"):
+        toks, counts = enc.tokens(d_in, off, window, finder=finder)
+        torch.cuda.synchronize()
+        assert int(counts[0]) == len(want), finder
+        assert (toks[:len(want)].cpu().numpy().view(np.uint32) == want).all(), finder
+
+
 def test_one_large_stream(sq, batch):
     """One 24 MB stream: more than 2^24 bytes (the index sort stops carrying the key byte in
     the element, lz77_index.hip) and more than 2^24 tokens (the entropy kernels stop batching
