@@ -7,10 +7,11 @@
 //       squeeze.h:476-500 squeeze_read_pos
 //     With the trees held still, lane l decodes the token that would start at bit l of a
 //     staged piece of the stream; the real starts are picked by following the lengths, and
-//     up to 64 tokens then update the trees at once (sqz_device.h: bump_lanes).  The token
+//     up to 64 tokens then update the trees at once (sqz_tree.h: bump_batch).  The token
 //     a step stops at (a restructure, an unseen symbol) takes the one-at-a-time path, where
-//     the root->leaf walk hands level d of the path to lane d.  Output: the same token words
-//     stage 1 of the encoder produces (literal / len<<16|dist).
+//     the leaf->root chain hands level d of the path to lane d; what was read ahead behind it
+//     is kept as far as the update left its codes alone.  Output: the same token words stage 1
+//     of the encoder produces (literal / len<<16|dist).
 //   lz_expand_kernel        one wavefront per stream: squeeze.h:521-539, 64 tokens per step.
 //     The window is the output buffer itself, read back through the L2: literals land in
 //     parallel, short back references are copied by their own lanes side by side, the rest by
@@ -93,12 +94,11 @@ __device__ __forceinline__ int peek_symbol(BitSource& r, const T& t) {
     return node;
 }
 
-// Up to 64 tokens per step (sqz_device.h: bump_lanes): the tokens are first read ahead
+// Up to 64 tokens per step (sqz_tree.h: bump_batch): the tokens are first read ahead
 // with both trees held still -- valid as long as no link changes, which is exactly what
-// bump_lanes then establishes for a prefix of them; the token the step stops at (NYT
-// escape, a restructuring update, malformed input) is decoded again by the
-// one-at-a-time path from its own bit position, so errors and updates are the
-// reference's.
+// bump_batch then establishes for a prefix of them; the token the step stops at takes the
+// one-at-a-time updates (and, if it is an NYT escape or malformed input, is decoded again
+// from its own bit position), so errors and updates are the reference's.
 __global__ __launch_bounds__(kWave, 4)          // four waves per SIMD: 16 streams per CU (the LDS allows as many)
 void entropy_decode_kernel(const uint8_t* __restrict__ in,
                            const uint64_t* __restrict__ in_off,

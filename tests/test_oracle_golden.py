@@ -156,7 +156,7 @@ def test_against_reference_build():
 
 
 def test_tree_invariants_the_kernels_rely_on():
-    """The batched update in the HIP kernels (sqz_device.h: LaneWalk::level) drops two tests
+    """The batched update in the HIP kernels (sqz_tree.h: bump_batch) drops two tests
     because of two properties of the tree at rest: every sibling pair is ordered (lo <= hi) and
     every node below the root has a sibling once the tree holds two leaves.  The oracle built
     with -DSQZO_CHECK_INVARIANTS asserts both after EVERY update (it aborts otherwise)."""

@@ -15,7 +15,7 @@ if run: segs.append(run)
 segs=np.array(segs); print("steps",len(a),"events",len(segs),"tokens",segs.sum(), "mean seg %.1f"%segs.mean())
 R_TOK=6.9          # tokens found per read-ahead round
 C_ROUND=2900+760   # cycles per round incl. hops
-C_STEP=10700+1500  # bump_lanes + post/store per step
+C_STEP=10700+1500  # round-1 figures: batched update + post/store per step
 def simulate(policy, name):
     cyc=0; steps=0; rounds=0; state=policy.init()
     for s in segs:                      # s clean tokens, then an event (exact path, cost not policy dependent)
