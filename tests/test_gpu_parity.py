@@ -454,6 +454,53 @@ def test_caller_tokens_are_validated(sq, batch):
             assert err[b] == errno.EINVAL, (name, err[b])
 
 
+def _mixed_blocks(seed, n_blocks, size):
+    """inputs whose statistics move: alphabets that grow, shrink and drift, runs, repeats of earlier
+    pieces, near-uniform stretches -- trees that keep restructuring, symbols that show up late"""
+    rng = random.Random(seed)
+    blocks = []
+    for _ in range(n_blocks):
+        out = bytearray()
+        while len(out) < size:
+            kind = rng.randrange(6)
+            n = rng.randrange(50, 4000)
+            if kind == 0:                                   # small alphabet, skewed
+                k = rng.randrange(2, 12)
+                alpha = [rng.randrange(256) for _ in range(k)]
+                out += bytes(alpha[min(int(rng.expovariate(0.9)), k - 1)] for _ in range(n))
+            elif kind == 1:                                 # near-uniform over a window of values
+                lo, span = rng.randrange(200), rng.randrange(8, 56)
+                out += bytes(lo + rng.randrange(span) for _ in range(n))
+            elif kind == 2 and len(out) > 100:              # an earlier piece again
+                a = rng.randrange(len(out) - 50)
+                out += out[a:a + min(n, len(out) - a)]
+            elif kind == 3:                                 # a run
+                out += bytes([rng.randrange(256)]) * rng.randrange(3, 400)
+            elif kind == 4:                                 # all 256 values, drifting
+                base = rng.randrange(256)
+                out += bytes((base + int(rng.gauss(0, 20))) & 0xFF for _ in range(n))
+            else:                                           # short period
+                p = bytes(rng.randrange(256) for _ in range(rng.randrange(2, 9)))
+                out += p * (n // len(p))
+        blocks.append(bytes(out[:size]))
+    return blocks
+
+
+@pytest.mark.parametrize("window", [1 << 10, 1 << 13])
+def test_moving_statistics(sq, batch, window):
+    """40 blocks of 40 KB with statistics that keep moving: every stream equals the oracle's and
+    decodes back (the batched update, the exact path and the decoder's kept read-ahead all at work)"""
+    blocks = _mixed_blocks(window, 40, 40000)
+    outs, err = batch.encode_blocks_host(blocks, window)
+    assert not any(err)
+    want = [O.encode(c, 15, header=False, window=window) for c in blocks]
+    for b in range(len(blocks)):
+        assert outs[b] == want[b], b
+    back, derr = batch.decode_blocks_host(want, [len(c) for c in blocks])
+    assert not any(derr)
+    assert back == blocks
+
+
 def deep_tree_literals(limit=1.2e7, ratio=1.7):
     """literals in blocks, every new symbol about `ratio` times as frequent as the one before: the
     shape that drives huffman.h's tree deep with the fewest symbols (ratio 2 gives depth = number
