@@ -123,10 +123,33 @@ def decode(D, streams, sizes):
     return [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(n)], err
 
 
+def _moving(size, seed=9):
+    """statistics that keep moving (small alphabets, drifting values, runs, repeats): the trees keep
+    restructuring, which is what the decoder's kept read-ahead has to survive"""
+    import random
+    rng = random.Random(seed)
+    out = bytearray()
+    while len(out) < size:
+        kind, n = rng.randrange(4), rng.randrange(30, 600)
+        if kind == 0:
+            alpha = [rng.randrange(256) for _ in range(rng.randrange(2, 10))]
+            out += bytes(rng.choice(alpha) for _ in range(n))
+        elif kind == 1:
+            base = rng.randrange(256)
+            out += bytes((base + int(rng.gauss(0, 12))) & 0xFF for _ in range(n))
+        elif kind == 2 and len(out) > 60:
+            a = rng.randrange(len(out) - 40)
+            out += out[a:a + min(n, len(out) - a)]
+        else:
+            out += bytes([rng.randrange(256)]) * rng.randrange(3, 80)
+    return bytes(out[:size])
+
+
 def test_streams_equal_the_oracle(emu):
     name, E, D, enc_oracle = emu
     cases = [O.corpus("laozi.txt")[:9000], O.zipf_block(3, 7000), b"", b"a", b"abcabcabc" * 40,
-             bytes(range(256)) * 6, bytes(3000), O.corpus("confucius.txt")[20000:26000]]
+             bytes(range(256)) * 6, bytes(3000), O.corpus("confucius.txt")[20000:26000],
+             _moving(6000)]
     w = 1 << 12
     outs, err = emit(E, [O.tokens(c, w) for c in cases], [max(len(c), 1) for c in cases])
     want = [enc_oracle(c, w) for c in cases]
