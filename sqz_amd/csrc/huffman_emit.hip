@@ -425,7 +425,7 @@ __device__ __forceinline__ void debug_drive(T& t, DbgLit& lit, DbgPos& pos, Emit
                                             uint32_t max_steps, uint32_t& consumed) {
     uint32_t k = 0;
     for (uint32_t step = 0; k < count && t.fault == 0 && (max_steps == 0 || step < max_steps); step++) {
-        if (stop_early && t.aux == 0) { break; }               // (bisecting: do not crawl on after the intervals are lost)
+        if (stop_early && t.aux == 0) { break; }               // (bisecting: do not crawl on after the positions are given up)
         int sym = -1;
         if (k + (uint32_t)lane < count) { sym = symbols[k + lane]; }
         const bool valid = sym >= 0 && sym < T::kLeaves && lane < batch;

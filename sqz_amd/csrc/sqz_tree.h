@@ -3,7 +3,7 @@
 //
 // Reference semantics restated here (file:line relative to /root/reference/attic/map_experiment):
 //   huffman.h:13-34   node / tree           -> TreeLds (three words per node), Tree<> (registers)
-//   huffman.h:41-62   huffman_update_paths  -> depths, codes and leaf intervals kept by FLAT passes
+//   huffman.h:41-62   huffman_update_paths  -> depths, codes and leaf positions kept by FLAT passes
 //                                              (swap_fix / promote_fix / the insert's shift) + the
 //                                              depth mark (mark_subtree); relabel() for deep trees
 //   huffman.h:64-86   huffman_swap_siblings -> order_only (+ swap_fix), the per-level swaps of climb_wave
@@ -34,7 +34,7 @@
 // remembers those two leaves (not the numbers: an insert shifts positions, leaf identities stay).
 // With P = inclusive prefix sums of the batch's histogram over positions,
 // n(v) = P[pos(last(v))] - P[pos(first(v)) - 1] for ALL nodes at once: independent lookups per
-// node (ten nodes per lane) instead of two dependent walks per token with an LDS atomic on every
+// node (eight probes per lane) instead of two dependent walks per token with an LDS atomic on every
 // level.  A node's test partner (sibling for a lo child, uncle for a hi child) is cached next to
 // its ends.  If node v fails its test, the first token that may not be applied is the
 // (f(partner) - f(v) + 1)-th one whose position lies below v; the earliest such token over all
@@ -97,7 +97,7 @@ constexpr int kDepthShift = 24;
 #define SQZ_FREEZE_DEPTH 63                   // huffman.h:228 `t->depth < 63`
 #endif
 #ifndef SQZ_BATCH_TOKENS
-#define SQZ_BATCH_TOKENS ((1u << 24) - 256u)  // a count word holds 24 bits while the intervals are kept
+#define SQZ_BATCH_TOKENS ((1u << 24) - 256u)  // a count word holds 24 bits while the positions are kept
 #endif
 constexpr uint32_t kBatchTokens = SQZ_BATCH_TOKENS;
 constexpr int kAuxDepth = SQZ_AUX_DEPTH;
