@@ -19,6 +19,11 @@ the hot path over one batch of synthetic input that is already resident in HBM.
           (SURVEY.md section 8d config 4 asks for both figures).
   --scaling weak  keeps the round-1 measurement (every rank its own --blocks batch).
 
+  --codec rc   measures SURVEY.md section 8f-1 instead: the reference's HEAD ("R-era") adaptive range
+               coder (src/sqz.c:506-548,717-743; literal-only, the finders are compiled out at HEAD)
+               on the same batch, with its own roofline (rc_encode_kernel) and CPU baseline
+               (oracle/_ref/libsqz_ref_rc.so).  Not BASELINE.json's metric: a secondary line.
+
 The decode pass over the produced streams is timed right after, with the same K and W, and
 reported in the same line (`decode_MBps`), together with
   roofline      the dominant kernel of the encode step (longest average launch, HIP
@@ -103,6 +108,144 @@ def measured_traffic(kernel):
     return int(k["hbm_bytes_per_launch"]), cur.get("method")
 
 
+def cpu_baseline_rc(n_sample_blocks, block_bytes):
+    """single-thread CPU MB/s of the R-era coder on blocks [0, n_sample_blocks): the reference's own
+    src/sqz.c (oracle/_ref/libsqz_ref_rc.so) when it was built, else the oracle restatement."""
+    import ctypes as C
+    import oracle_lib as O       # checker only: TEST INFRASTRUCTURE
+    path = os.path.join(O.ODIR, "_ref", "libsqz_ref_rc.so")
+    ref = C.CDLL(path) if os.path.exists(path) else None
+    kind = "reference" if ref is not None else "port"
+    enc_s = dec_s = 0.0
+    total = 0
+    for b in range(n_sample_blocks):
+        data = O.zipf_block(b, block_bytes)
+        cap = 2 * block_bytes + 64
+        out = C.create_string_buffer(cap)
+        n = C.c_uint64()
+        t0 = time.perf_counter()
+        if ref is not None:
+            e = ref.sqz_ref_rc_compress(data, C.c_uint64(block_bytes), C.c_uint32(1 << 15), out, C.c_uint64(cap), C.byref(n))
+        else:
+            e = O.ORACLE.sqzo_rc_encode(data, C.c_uint64(block_bytes), out, C.c_uint64(cap), C.byref(n))
+        enc_s += time.perf_counter() - t0
+        assert e == 0
+        back = C.create_string_buffer(block_bytes)
+        nb, cons = C.c_uint64(), C.c_uint64()
+        t0 = time.perf_counter()
+        if ref is not None:
+            e = ref.sqz_ref_rc_decompress(out, C.c_uint64(n.value), back, C.c_uint64(block_bytes), C.byref(nb), C.byref(cons))
+        else:
+            e = O.ORACLE.sqzo_rc_decode(out, C.c_uint64(n.value), back, C.c_uint64(block_bytes), C.byref(nb), C.byref(cons))
+        dec_s += time.perf_counter() - t0
+        assert e == 0 and back.raw == data
+        total += block_bytes
+    return {"value": round(total / enc_s / 1e6, 4), "unit": "MB/s", "cores": 1, "kind": kind,
+            "decode_value": round(total / dec_s / 1e6, 4),
+            "sample": f"Zipf blocks 0..{n_sample_blocks - 1} of the same workload ({n_sample_blocks} x {block_bytes} B), "
+                      f"encode {enc_s:.2f} s + decode {dec_s:.2f} s on one host core of {os.cpu_count()}"}
+
+
+def run_rc(args, torch, dist, batch, shard, info, dev, comm_dev, rank, world, lo, n, total_blocks, strong):
+    """the R-era coder (src/sqz.c:506-548,717-743) on the same batch.  One wave per
+    stream; encode = rc_encode_kernel, decode = rc_decode_kernel; same K / W / barrier contract."""
+    import ctypes as C
+    from sqz_amd import _native as N
+    L = N.lib()
+    bb = args.block_bytes
+    d_in = batch.zipf_blocks(n, bb, first_block=lo, device=dev)
+    in_off = batch.uniform_offsets(n, bb, device=dev)
+    cap = (int(L.sqz_rc_bound(bb)) + 7) // 8 * 8
+    out_off = batch.uniform_offsets(n, cap, device=dev)
+    out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    ob = torch.zeros(n, dtype=torch.int64, device=dev)
+    err = torch.zeros(n, dtype=torch.int32, device=dev)
+    back = torch.empty_like(d_in)
+    db = torch.zeros(n, dtype=torch.int64, device=dev)
+    cons = torch.zeros(n, dtype=torch.int64, device=dev)
+    derr = torch.zeros(n, dtype=torch.int32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def enc_step():
+        assert L.sqz_hip_rc_encode_blocks(P(d_in), P(in_off), n, P(out), P(out_off), P(ob), P(err), st()) == 0
+
+    def dec_step():
+        assert L.sqz_hip_rc_decode_blocks(P(out), P(out_off), n, P(back), P(in_off), P(db), P(cons), P(derr), st()) == 0
+
+    for _ in range(args.warmup):
+        enc_step()
+    barrier()
+    batch.set_timing(True)
+    batch.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc_step()
+    barrier()
+    enc_s = time.perf_counter() - t0
+    tim = batch.get_timing(reset=True)
+    assert int(err.abs().sum()) == 0, "rc encode reported errors"
+    for _ in range(args.warmup):
+        dec_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec_step()
+    barrier()
+    dec_s = time.perf_counter() - t0
+    dtim = batch.get_timing(reset=True)
+    batch.set_timing(False)
+    assert int(derr.abs().sum()) == 0, "rc decode reported errors"
+    if not args.no_verify:
+        assert torch.equal(back, d_in), "rc round trip differs"
+        assert torch.equal(cons, ob), "rc decoder did not consume exactly the stream"
+    comp_bytes = int(ob.sum().item())
+    if world > 1:
+        enc_s = shard.max_over_ranks(enc_s, comm_dev)
+        dec_s = shard.max_over_ranks(dec_s, comm_dev)
+        comp_total = shard.sum_over_ranks(float(comp_bytes), comm_dev)
+    else:
+        comp_total = float(comp_bytes)
+    if rank != 0:
+        return
+    in_total = float(total_blocks) * bb
+    enc_ms = tim["rc_encode_kernel"][0] / max(tim["rc_encode_kernel"][1], 1)
+    dec_ms = dtim["rc_decode_kernel"][0] / max(dtim["rc_decode_kernel"][1], 1)
+    algo = n * bb + comp_bytes                   # SURVEY.md 8d: every input byte read once, every output byte written once
+    achieved = algo / (enc_ms * 1e-3) / 1e9
+    line = {
+        "metric": "R-era range coder (SURVEY.md 8f-1): encode MB/s + decode MB/s, batched blocks",
+        "value": round(in_total / enc_s * args.steps / 1e6, 3), "unit": "MB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(enc_s / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{total_blocks} x {bb} B Zipf(s=1) byte blocks, one independent stream per block, "
+                               "adaptive order-0 range coder of the reference's HEAD (literal-only as HEAD's encoder "
+                               "runs, src/sqz.c:590-596,717-743) -- NOT BASELINE.json's metric, a secondary line",
+                   "total_blocks": total_blocks, "blocks_per_gpu": n, "block_bytes": bb, "codec": "rc",
+                   "device": info["name"]},
+        "decode_MBps": round(in_total / dec_s * args.steps / 1e6, 3),
+        "decode_ms_per_step": round(dec_s / args.steps * 1e3, 3),
+        "compressed_ratio": round(comp_total / in_total, 5),
+        "kernels_ms": {"rc_encode_kernel": round(enc_ms, 3), "rc_decode_kernel": round(dec_ms, 3)},
+        "roofline": {"bound": "hbm", "kernel": "rc_encode_kernel", "achieved": round(achieved, 4),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 7),
+                     "traffic": None, "traffic_note": "no PMC pass for the R-era kernels",
+                     "algorithmic_bytes_per_launch": algo,
+                     "decode_frac_of_hbm_roof": round(algo / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 7)},
+    }
+    if world == 1 and args.cpu_blocks > 0:
+        line["cpu_baseline"] = cpu_baseline_rc(args.cpu_blocks, bb)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +262,9 @@ def main():
                     help="N>1, strong: skip the scatter/gather-inclusive measurement")
     ap.add_argument("--cpu-blocks", type=int, default=8, help="CPU baseline sample: blocks 0..7 (SURVEY.md 8d), about 26 s of one host core (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--codec", choices=["huffman", "rc"], default="huffman",
+                    help="huffman = BASELINE.json's path (LZ77 + adaptive Huffman, H0); rc = the R-era range coder "
+                         "of HEAD (SURVEY.md section 8f-1), a secondary line")
     ap.add_argument("--finder", choices=["index", "scan"], default="index",
                     help="stage-1 match finder: index (default) or the brute-force scan")
     args = ap.parse_args()
@@ -155,6 +301,11 @@ def main():
         else (rank * args.blocks, (rank + 1) * args.blocks)
     n = hi - lo                                    # blocks this rank owns
     info = sqz_amd.device_info()
+    if args.codec == "rc":
+        run_rc(args, torch, dist, batch, shard, info, dev, comm_dev, rank, world, lo, n, total_blocks, strong)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     batch.set_finder(args.finder)
 
     # ---- synthetic input, generated straight into HBM ------------------------
@@ -230,57 +381,100 @@ def main():
         tokens_all = tokens_rank
 
     # ---- N>1, strong: the same step with the batch starting and ending on rank 0 --------
-    # (after every collective the device-local line needs: a failure here cannot take that line down)
+    # (after every collective the device-local line needs: a failure here cannot take that line down).
+    # A rank that raised must not leave its peers blocked inside the next collective, so the leg is cut
+    # into PHASES: what can fail on one rank alone (allocation, the local encode, the checks) runs between
+    # collectives inside phase(); every phase ends with an all_reduce(MIN) of an ok flag, and once any
+    # rank has failed ALL ranks skip the remaining collectives of the leg together.
     xfer = None
     if world > 1 and strong and not args.no_transfer:
-        try:
-            root_in = batch.zipf_blocks(total_blocks, bb, first_block=0, device=dev) if rank == 0 else None
-            if root_in is not None and comm_dev.type == "cpu":
-                root_in = root_in.cpu()
-            dense_buf = torch.empty(n * (sqz_amd.bound(bb) // 8 * 8), dtype=torch.uint8, device=dev)
-            parts = {"scatter": 0.0, "encode": 0.0, "gather": 0.0}
+        state = {"ok": True, "why": ""}
 
-            def transfer_step(timed):
-                t_a = time.perf_counter()
-                mine, span = shard.scatter_blocks(root_in, total_blocks, bb, comm_dev)
-                mine = mine.to(dev)
-                torch.cuda.synchronize()
-                t_b = time.perf_counter()
-                o, o_off, o_bytes, e = enc.encode(mine, in_off, 1 << wb)
-                dense, d_off = batch.pack_blocks(o, o_off, o_bytes, dense=dense_buf)
-                torch.cuda.synchronize()
-                t_c = time.perf_counter()
-                res = shard.gather_dense(dense, o_bytes, total_blocks, comm_dev)
-                torch.cuda.synchronize()
-                t_d = time.perf_counter()
-                if timed:
-                    parts["scatter"] += t_b - t_a
-                    parts["encode"] += t_c - t_b
-                    parts["gather"] += t_d - t_c
-                return res
+        def phase(fn):
+            """run fn on every rank that is still ok, then agree on the outcome"""
+            res = None
+            if state["ok"]:
+                try:
+                    res = fn()
+                except Exception as ex:                      # noqa: BLE001 -- reported in the line
+                    state["ok"] = False
+                    state["why"] = f"{type(ex).__name__}: {ex}"[:400]
+            agreed = shard.min_over_ranks(1.0 if state["ok"] else 0.0, comm_dev) > 0.5
+            if not agreed and state["ok"]:
+                state["ok"] = False
+                state["why"] = "another rank failed in this phase"
+            return res
 
-            for _ in range(args.warmup):
-                transfer_step(False)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                root_dense, root_sizes, root_off = transfer_step(True)
-            barrier()
-            x_s = shard.max_over_ranks(time.perf_counter() - t0, comm_dev)
-            if rank == 0:
-                # what came back is the batch's streams in block order: rank 0's own range must
-                # equal what it encoded locally, and the sizes must add up to the job's total
-                own = root_dense[:int(root_off[n])].to(dev)
-                loc_dense, loc_off = batch.pack_blocks(out, out_off, out_bytes)
-                assert torch.equal(own, loc_dense[:own.numel()]), "gathered streams differ from the local encode"
-                xfer = {"encode_MBps": round(total_blocks * bb / x_s * args.steps / 1e6, 3),
-                        "ms_per_step": round(x_s / args.steps * 1e3, 3),
-                        "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
-                        "gathered_bytes": int(root_off[-1]),
-                        "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
-                                f"dense streams (point-to-point per peer) -> rank 0, backend {backend}"}
-        except Exception as ex:        # the device-local line above stands whatever the transfer leg does
-            xfer = {"error": f"{type(ex).__name__}: {ex}"[:400]}
+        parts = {"scatter": 0.0, "encode": 0.0, "gather": 0.0}
+        hold = {}
+
+        def setup():
+            hold["root_in"] = batch.zipf_blocks(total_blocks, bb, first_block=0, device=dev) if rank == 0 else None
+            if hold["root_in"] is not None and comm_dev.type == "cpu":
+                hold["root_in"] = hold["root_in"].cpu()
+            hold["dense_buf"] = torch.empty(n * (sqz_amd.bound(bb) // 8 * 8), dtype=torch.uint8, device=dev)
+
+        phase(setup)
+
+        def transfer_step(timed):
+            t = [time.perf_counter()]
+
+            def scatter():
+                mine, _span = shard.scatter_blocks(hold["root_in"], total_blocks, bb, comm_dev)
+                hold["mine"] = mine.to(dev)
+                torch.cuda.synchronize()
+            phase(scatter)
+            t.append(time.perf_counter())
+
+            def local():
+                o, o_off, o_bytes, _e = enc.encode(hold["mine"], in_off, 1 << wb)
+                hold["dense"], _ = batch.pack_blocks(o, o_off, o_bytes, dense=hold["dense_buf"])
+                hold["o_bytes"] = o_bytes
+                torch.cuda.synchronize()
+            phase(local)
+            t.append(time.perf_counter())
+
+            def gather():
+                hold["res"] = shard.gather_dense(hold["dense"], hold["o_bytes"], total_blocks, comm_dev)
+                torch.cuda.synchronize()
+            phase(gather)
+            t.append(time.perf_counter())
+            if timed:
+                parts["scatter"] += t[1] - t[0]
+                parts["encode"] += t[2] - t[1]
+                parts["gather"] += t[3] - t[2]
+
+        for _ in range(args.warmup):
+            transfer_step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            transfer_step(True)
+        barrier()
+        x_s = shard.max_over_ranks(time.perf_counter() - t0, comm_dev)
+
+        def check():
+            if rank != 0:
+                return None
+            root_dense, _root_sizes, root_off = hold["res"]
+            # what came back is the batch's streams in block order: rank 0's own range must
+            # equal what it encoded locally, and the sizes must add up to the job's total
+            own = root_dense[:int(root_off[n])].to(dev)
+            loc_dense, _loc_off = batch.pack_blocks(out, out_off, out_bytes)
+            assert torch.equal(own, loc_dense[:own.numel()]), "gathered streams differ from the local encode"
+            return {"encode_MBps": round(total_blocks * bb / x_s * args.steps / 1e6, 3),
+                    "ms_per_step": round(x_s / args.steps * 1e3, 3),
+                    "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
+                    "gathered_bytes": int(root_off[-1]),
+                    "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
+                            f"dense streams (point-to-point per peer) -> rank 0, backend {backend}",
+                    # what stands behind this leg until a multi-GPU run has been recorded
+                    "evidence": "shard.py over RCCL: world-1 nccl test on one MI355X (tests/test_shard_nccl.py); "
+                                "world-2: gloo rehearsal only (tests/test_shard_gpu.py, tools/rehearse_n2.sh)"}
+
+        xfer = phase(check)
+        if not state["ok"]:
+            xfer = {"error": state["why"]}          # on EVERY rank: they all leave with the same exit code
 
     if rank == 0:
         in_total = float(total_blocks) * bb
@@ -346,7 +540,7 @@ def main():
         # the candidate tests the reference's O(window) scan makes for the same tokens (block 0 of
         # this rank x its blocks).  Only --finder scan PERFORMS them; the indexed finder visits the
         # equal-prefix candidates only, so for it the figure is what it avoids, not a rate it achieves.
-        cand = cand0 * n * (world if strong else world)
+        cand = cand0 * total_blocks                 # block 0 of rank 0 stands for every block of the job
         if args.finder == "scan":
             sec["scan_candidate_tests_per_step"] = cand
             sec["scan_candidate_tests_per_s"] = round(cand / (ms_per_step * 1e-3), 1)
@@ -359,6 +553,10 @@ def main():
 
     if world > 1:
         dist.destroy_process_group()
+    if isinstance(xfer, dict) and "error" in xfer:
+        # the device-local line is out; the failed transfer leg must not pass for a clean run
+        print(f"bench.py: with_transfer leg failed on rank {rank}: {xfer['error']}", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

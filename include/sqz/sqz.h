@@ -47,6 +47,26 @@ enum {
     sqz_header_bits  = 72   /* squeeze.h:255-265: 64 (bytes) + 8 (win_bits) */
 };
 
+/* The public constants of the H0 header under the reference's own names (squeeze.h:9-25), same
+ * values: what a caller of the `squeeze` vtable compiles against (attic/map_experiment/test.c
+ * passes win_bits in [squeeze_min_win_bits, squeeze_max_win_bits] and sizes init_with's block
+ * with squeeze_sizeof).                                                                      */
+enum {
+    squeeze_deflate_sym_min = 257,  /* squeeze.h:10 first length symbol of the literal/length alphabet */
+    squeeze_deflate_sym_max = 284,  /* squeeze.h:11 last one                                           */
+    squeeze_deflate_pos_max = 29,   /* squeeze.h:12 last distance code                                 */
+    squeeze_deflate_len_min = 3,    /* squeeze.h:13 */
+    squeeze_deflate_len_max = 257   /* squeeze.h:15 */
+};
+enum {
+    squeeze_min_win_bits = 10,      /* squeeze.h:19 */
+    squeeze_max_win_bits = 15,      /* squeeze.h:20 */
+    squeeze_min_map_bits = 16,      /* squeeze.h:21 (the map experiment: map_bits != 0 is refused here) */
+    squeeze_max_map_bits = 28,      /* squeeze.h:22 */
+    squeeze_lit_nyt = squeeze_deflate_sym_max + 1,   /* squeeze.h:23 = 285 */
+    squeeze_pos_nyt = squeeze_deflate_pos_max + 1    /* squeeze.h:24 = 30  */
+};
+
 /* ------------------------------------------------------------------ */
 /* Bit stream: `bitstream` of attic/map_experiment/bitstream.h:7-18, same fields in the same
  * order, so the reference's designated initialisers compile unchanged
@@ -67,10 +87,14 @@ enum {
  *   reader  words are pulled with bs->input(bs) (bs->b64 = the word, bitstream.h:83) into a host
  *           buffer and decoded from there.  The reference pulls a word when its bit reader
  *           runs dry; the device decodes a whole buffer at once, so the shim pulls ahead:
- *           first what a stream of `bytes` bytes takes at a 1:1 ratio, then twice as much each
- *           time the decoder runs dry (E2BIG).  At most twice the words the reference would
- *           have consumed are pulled; a callback error only surfaces if the decoder needed
- *           words beyond it.  bs->read / bs->bits / bs->b64 are left as the reference's
+ *           4 words first, then twice as many each time the decoder runs dry (E2BIG), decoding
+ *           again from the start.  OVER-READ BOUND: the words pulled are at most
+ *           max(4, 2 x the words the stream holds), whatever its compression ratio -- the
+ *           reference pulls exactly the words the stream holds (bitstream.h:81-85), so a
+ *           caller whose source continues behind the stream (another record in the same file)
+ *           must re-position the source from bs->read, which IS the reference's figure; a
+ *           pulled word cannot be handed back.  A callback error only surfaces if the decoder
+ *           needed words beyond it.  bs->read / bs->bits / bs->b64 are left as the reference's
  *           reader would leave them (read = words the DECODER consumed x 8).               */
 typedef struct bitstream {
     void*    stream;   /* callback context (bitstream.h:8); exclusive with (data, capacity) */
@@ -95,9 +119,19 @@ struct sqz {
     int32_t  device;      /* HIP device ordinal used by the last call, -1 = default */
     uint64_t tokens;      /* LZ77 tokens of the last sqz_compress */
     struct bitstream* bs; /* squeeze.h:89: set by compress / decompress */
-    uint64_t reserved[4];
+    void*    stream;      /* optional hipStream_t the call's copies and kernels are enqueued on; NULL (what
+                           * sqz_init / alloc / init_with leave) = a stream of the library's own, one per
+                           * call in flight.  Calls from different threads do not serialise on each other:
+                           * every call stages through buffers of its own. */
+    uint64_t reserved[3];
 };
 typedef struct sqz sqz_type; /* README.md:128 */
+
+/* squeeze.h:94-107 squeeze_sizeof(map_bits): the size of the block `init_with` takes (squeeze.h:191-199).
+ * The reference lays its trees out behind the struct; here they live in the device's LDS for the duration of
+ * a call, so the block is the struct.  init_with accepts any size >= this (a caller that kept the reference's
+ * larger figure still passes); map_bits must be 0.                                                       */
+#define squeeze_sizeof(map_bits) (sizeof(struct sqz))
 
 /* shl/README.md:37-38  `static struct sqz s; sqz_init(&s);` */
 SQZ_API void sqz_init(struct sqz* s);
@@ -294,7 +328,9 @@ enum {
     SQZ_HIP_K_INDEX_MATCH = 4,    /* index_match_kernel  }                            */
     SQZ_HIP_K_INDEX_PARSE = 5,    /* index_parse_kernel  }                            */
     SQZ_HIP_K_LZ_EXPAND = 6,      /* lz_expand_kernel                                 */
-    SQZ_HIP_KERNELS = 8
+    SQZ_HIP_K_RC_ENCODE = 7,      /* rc_encode_kernel  } R-era range coder            */
+    SQZ_HIP_K_RC_DECODE = 8,      /* rc_decode_kernel  } (include/sqz/sqz_rc.h)       */
+    SQZ_HIP_KERNELS = 12
 };
 typedef struct sqz_hip_timing {
     float    ms[SQZ_HIP_KERNELS];        /* summed launch durations per kernel        */

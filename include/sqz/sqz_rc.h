@@ -21,9 +21,13 @@
  * cross to it, so the shim serves them: compress runs to a host buffer and hands every byte to
  * rc.write in order (stopping at the first error the callback raises in rc.error); decompress pulls
  * bytes with rc.read ahead of the decoder -- 64 bytes, then twice as much each time the decoder ran
- * past what was pulled (it starts over: the total work stays within twice the last attempt) -- so at
- * most twice the bytes the reference would have asked for, plus 64, are read; rc.low / rc.range /
- * rc.code are not meaningful after a call.
+ * past what was pulled (it starts over: the total work stays within twice the last attempt).
+ * OVER-READ BOUND: at most max(64, 2 x the bytes the reference would have asked for) are read through
+ * rc.read; the reference asks for exactly the stream (rc_consume, src/sqz.c:499-500), so a caller whose
+ * source continues behind the stream must re-position it itself.  A source that FAILS at its end (the
+ * callback sets rc.error, as the reference's own does, test.c:112-121) ends the decode where the
+ * reference's loop ends (:800-802): same return value, same rc.error.  rc.low / rc.range / rc.code are
+ * not meaningful after a call.
  * Errors are the reference's errno values in rc.error: EINVAL, EILSEQ (src/sqz.c:523-541), ERANGE,
  * ENOBUFS (:807-833), plus ENODEV (no gfx950 device: there is no CPU fallback) and ENOMEM.
  */

@@ -20,7 +20,7 @@
 #include "rt/ustd.h"           /* the reference's rt_printf / rt_swear implementations */
 #include "sqz/sqz.h"
 
-struct mem_io { uint8_t* out; uint64_t cap, written; const uint8_t* in; uint64_t avail, consumed; };
+struct mem_io { uint8_t* out; uint64_t cap, written; const uint8_t* in; uint64_t avail, consumed; int dry_error; };
 
 static void put(struct range_coder* rc, uint8_t b) {
     struct mem_io* io = (struct mem_io*)((struct sqz*)rc)->that;
@@ -31,6 +31,8 @@ static void put(struct range_coder* rc, uint8_t b) {
 static uint8_t get(struct range_coder* rc) {
     struct mem_io* io = (struct mem_io*)((struct sqz*)rc)->that;
     uint8_t b = 0;
+    /* a source that fails at its end reports it the way the reference's own callback does (test.c:112-121) */
+    if (io->dry_error != 0 && io->consumed >= io->avail && rc->error == 0) { rc->error = io->dry_error; }
     if (io->consumed < io->avail) { b = io->in[io->consumed]; }
     io->consumed++;
     return b;
@@ -41,7 +43,7 @@ int sqz_ref_rc_compress(const uint8_t* data, uint64_t bytes, uint32_t window, ui
                         uint64_t* out_bytes) {
     struct sqz* s = (struct sqz*)calloc(1, sizeof(struct sqz));
     if (s == NULL) { return ENOMEM; }
-    struct mem_io io = { out, cap, 0, NULL, 0, 0 };
+    struct mem_io io = { out, cap, 0, NULL, 0, 0, 0 };
     s->that = &io;
     sqz_init(s, NULL, 0);
     s->rc.write = put;
@@ -59,11 +61,19 @@ int sqz_ref_rc_compress(const uint8_t* data, uint64_t bytes, uint32_t window, ui
     return e;
 }
 
+int sqz_ref_rc_decompress_dry(const uint8_t* in, uint64_t in_bytes, uint8_t* data, uint64_t cap,
+                              uint64_t* out_bytes, uint64_t* consumed, int dry_error);
+
 int sqz_ref_rc_decompress(const uint8_t* in, uint64_t in_bytes, uint8_t* data, uint64_t cap,
                           uint64_t* out_bytes, uint64_t* consumed) {
+    return sqz_ref_rc_decompress_dry(in, in_bytes, data, cap, out_bytes, consumed, 0);
+}
+
+int sqz_ref_rc_decompress_dry(const uint8_t* in, uint64_t in_bytes, uint8_t* data, uint64_t cap,
+                              uint64_t* out_bytes, uint64_t* consumed, int dry_error) {
     struct sqz* s = (struct sqz*)calloc(1, sizeof(struct sqz));
     if (s == NULL) { return ENOMEM; }
-    struct mem_io io = { NULL, 0, 0, in, in_bytes, 0 };
+    struct mem_io io = { NULL, 0, 0, in, in_bytes, 0, dry_error };
     s->that = &io;
     sqz_init(s, NULL, 0);
     s->rc.read = get;

@@ -50,6 +50,7 @@ typedef struct {
     uint8_t* out; uint64_t cap, written;
     const uint8_t* in; uint64_t avail, consumed;
     int error;
+    int dry_error;             /* what a read past the end sets (0: nothing), see rc_get */
 } rc_state;
 
 static void rc_put(rc_state* rc) {                                /* rc_emit :474-479 */
@@ -83,7 +84,7 @@ static void rc_encode(rc_state* rc, rc_model* m, uint8_t sym) {   /* rc_encode :
 int sqzo_rc_encode(const uint8_t* data, uint64_t bytes, uint8_t* out, uint64_t capacity, uint64_t* out_bytes) {
     rc_model lit, size, byte;
     model_init(&lit, 2); model_init(&size, 256); model_init(&byte, 256);       /* sqz_init :550-565 */
-    rc_state rc = { 0, UINT64_MAX, 0, out, capacity, 0, NULL, 0, 0, 0 };       /* rc_init :485-490 */
+    rc_state rc = { 0, UINT64_MAX, 0, out, capacity, 0, NULL, 0, 0, 0, 0 };    /* rc_init :485-490 */
     for (uint64_t i = 0; i < bytes; i++) {
         rc_encode(&rc, &lit, 1);
         rc_encode(&rc, &byte, data[i]);
@@ -95,8 +96,12 @@ int sqzo_rc_encode(const uint8_t* data, uint64_t bytes, uint8_t* out, uint64_t c
     return rc.error;
 }
 
-static uint8_t rc_get(rc_state* rc) {              /* the harness's read callbacks return 0 past the end (test.c:113-122) */
+/* The harness's read callback returns 0 past the end AND carries its source's error into rc.error
+ * (test.c:112-121: `if (rc->error == 0) { b = io_get(io); rc->error = io->error; }`); dry_error is that
+ * source error (0 = a source that just ends, as an in-memory one does). */
+static uint8_t rc_get(rc_state* rc) {
     uint8_t b = 0;
+    if (rc->dry_error != 0 && rc->consumed >= rc->avail && rc->error == 0) { rc->error = rc->dry_error; }
     if (rc->consumed < rc->avail) { b = rc->in[rc->consumed]; }
     rc->consumed++;
     return b;
@@ -144,10 +149,16 @@ static uint8_t rc_decode(rc_state* rc, rc_model* m) {             /* rc_decode :
  * *out_bytes = bytes produced, *consumed = stream bytes the decoder asked for. */
 int sqzo_rc_decode(const uint8_t* in, uint64_t in_bytes, uint8_t* data, uint64_t capacity,
                    uint64_t* out_bytes, uint64_t* consumed) {
+    return sqzo_rc_decode_dry(in, in_bytes, data, capacity, out_bytes, consumed, 0);
+}
+
+/* the same with a source that FAILS at its end: the first read past it sets rc.error = dry_error */
+int sqzo_rc_decode_dry(const uint8_t* in, uint64_t in_bytes, uint8_t* data, uint64_t capacity,
+                       uint64_t* out_bytes, uint64_t* consumed, int dry_error) {
     rc_model lit, size, byte, bits, dist[32];
     model_init(&lit, 2); model_init(&size, 256); model_init(&byte, 256); model_init(&bits, 32);
     for (int b = 0; b < 32; b++) { model_init(&dist[b], 2); }
-    rc_state rc = { 0, UINT64_MAX, 0, NULL, 0, 0, in, in_bytes, 0, 0 };
+    rc_state rc = { 0, UINT64_MAX, 0, NULL, 0, 0, in, in_bytes, 0, 0, dry_error };
     for (int k = 0; k < 8; k++) { rc.code = (rc.code << 8) + rc_get(&rc); }   /* :794-797 */
     uint64_t i = 0;
     while (rc.error == 0) {

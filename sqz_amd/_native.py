@@ -24,12 +24,12 @@ Bitstream._fields_ = [("stream", C.c_void_p), ("data", C.POINTER(C.c_uint8)),
 class Sqz(C.Structure):
     """struct sqz / sqz_type of include/sqz/sqz.h."""
     _fields_ = [("error", C.c_int32), ("device", C.c_int32), ("tokens", C.c_uint64),
-                ("bs", C.POINTER(Bitstream)), ("reserved", C.c_uint64 * 4)]
+                ("bs", C.POINTER(Bitstream)), ("stream", C.c_void_p), ("reserved", C.c_uint64 * 3)]
 
 
 KERNEL_NAMES = ["lz77_scan_kernel", "huffman_emit_kernel", "entropy_decode_kernel",
                 "index_sort_kernel", "index_match_kernel", "index_parse_kernel",
-                "lz_expand_kernel", "reserved"]
+                "lz_expand_kernel", "rc_encode_kernel", "rc_decode_kernel", "reserved", "reserved", "reserved"]
 
 
 class BlockStats(C.Structure):
@@ -56,7 +56,7 @@ class SqzRc(C.Structure):
 
 class Timing(C.Structure):
     """sqz_hip_timing: per-kernel summed durations (HIP events on the launch stream)."""
-    _fields_ = [("ms", C.c_float * 8), ("launches", C.c_uint32 * 8)]
+    _fields_ = [("ms", C.c_float * 12), ("launches", C.c_uint32 * 12)]
 
 
 class SqueezeInterface(C.Structure):

@@ -147,7 +147,7 @@ def get_timing(reset=True):
     t = N.Timing()
     N.lib().sqz_hip_get_timing(C.byref(t), 1 if reset else 0)
     return {N.KERNEL_NAMES[k]: (float(t.ms[k]), int(t.launches[k]))
-            for k in range(8) if t.launches[k] > 0}
+            for k in range(len(N.KERNEL_NAMES)) if t.launches[k] > 0}
 
 
 # ---- host-buffer flavour (numpy in / numpy out) ------------------------------

@@ -48,15 +48,41 @@ def _deps():
 
 
 def _run_all(cmds, verbose):
-    """the library builds are independent hipcc runs of ~80 s each: start them together"""
+    """the library builds are independent hipcc runs of ~80 s each: start them together.
+
+    Every library is linked under a temporary name and moved into place (os.replace) once its own
+    hipcc has succeeded, so nothing can load a half-written .so; on the first failure the other
+    compilers are terminated and ALL of them are waited for before the error is raised."""
     procs = []
     for cmd in cmds:
+        final = cmd[cmd.index("-o") + 1]
+        tmp = final + f".tmp{os.getpid()}"
+        run = list(cmd)
+        run[run.index("-o") + 1] = tmp
         if verbose:
             print("[sqz_amd.build]", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+        procs.append((cmd, tmp, final, subprocess.Popen(run)))
+    failed = None
+    pending = list(procs)
+    while pending:
+        for item in list(pending):
+            cmd, tmp, final, p = item
+            try:
+                rc = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(item)
+            if rc == 0 and failed is None:
+                os.replace(tmp, final)
+            elif rc != 0 and failed is None:
+                failed = (rc, cmd)
+                for _, _, _, q in pending:          # stop the rest; the loop still waits for each
+                    q.terminate()
+    for _, tmp, _, _ in procs:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    if failed is not None:
+        raise subprocess.CalledProcessError(failed[0], failed[1])
 
 
 def build_native(force=False, verbose=True, variants=False):

@@ -41,18 +41,55 @@ struct DevBuf {
 };
 
 struct Ctx {
-    std::mutex mu;
+    std::mutex mu;                  // guards the probe only: no call holds it while the device works
     int  state = 0;                 // 0 = unprobed, 1 = ok, -1 = no device
     char name[256] = {0};
     int  cus = 0;
     uint64_t lds = 0;
-    // staging pool of the host-buffer flavour (grow-only, guarded by mu)
+};
+
+Ctx& ctx() { static Ctx c; return c; }
+
+// Staging of the host-buffer flavour: one LANE per call in flight -- grow-only device buffers and a
+// HIP stream of its own (SURVEY.md section 8b "Threading": one stream per call or caller-provided).
+// A call leases a lane for its H2D -> kernels -> D2H and hands it back; concurrent callers get
+// different lanes, so two threads neither serialise on a lock nor share the NULL stream.
+struct Lane {
+    hipStream_t own = nullptr;      // created with the lane (non-blocking: independent of the NULL stream)
     DevBuf in, out, in_off, out_off, tokens, tok_count, out_bytes, err, end_bit, work_a, work_m,
            dense, dense_off;
     std::vector<uint8_t> host_dense;   // landing area of the host flavour's one device-to-host copy
 };
 
-Ctx& ctx() { static Ctx c; return c; }
+struct LanePool {
+    std::mutex mu;
+    std::vector<Lane*> idle;
+    std::atomic<int> made{0};
+};
+LanePool& lanes() { static LanePool p; return p; }
+
+struct LaneLease {
+    Lane* lane = nullptr;
+    LaneLease() {
+        LanePool& p = lanes();
+        {
+            std::lock_guard<std::mutex> g(p.mu);
+            if (!p.idle.empty()) { lane = p.idle.back(); p.idle.pop_back(); }
+        }
+        if (lane == nullptr) {
+            lane = new Lane();
+            if (hipStreamCreateWithFlags(&lane->own, hipStreamNonBlocking) != hipSuccess) { lane->own = nullptr; }
+            p.made.fetch_add(1);
+        }
+    }
+    ~LaneLease() {
+        LanePool& p = lanes();
+        std::lock_guard<std::mutex> g(p.mu);
+        p.idle.push_back(lane);
+    }
+    // the caller's stream (struct sqz.stream) when given, else the lane's own
+    hipStream_t stream(void* callers) const { return callers != nullptr ? (hipStream_t)callers : lane->own; }
+};
 
 int probe_locked(Ctx& c) {
     if (c.state != 0) { return c.state > 0 ? 0 : ENODEV; }
@@ -73,6 +110,12 @@ int probe_locked(Ctx& c) {
     c.lds = (uint64_t)prop.maxSharedMemoryPerMultiProcessor;
     c.state = 1;
     return 0;
+}
+
+int device_ready(void) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return probe_locked(c);
 }
 
 int hip_errno(hipError_t e) {
@@ -277,8 +320,8 @@ void run_encode(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
 }
 
 // host-buffer encode of n blocks; prefix = pending header bits of block 0
-// (single-stream API only).  Caller holds ctx().mu.
-int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32_t n,
+// (single-stream API only).  `c` is the caller's leased lane, `st` the stream of this call.
+int encode_host(Lane& c, hipStream_t st, const uint8_t* in, const uint64_t* in_off, uint32_t n,
                        uint32_t window, uint8_t* out, const uint64_t* out_off,
                        uint64_t* out_bytes, int32_t* err,
                        uint64_t prefix_acc, int prefix_fill, uint64_t* tokens_total) {
@@ -295,7 +338,6 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
         (e = c.out_bytes.reserve((size_t)n * 8)) || (e = c.err.reserve((size_t)n * 4))) {
         return e;
     }
-    hipStream_t st = nullptr;
     if (total_in > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in + in_base, total_in, hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -346,9 +388,9 @@ int encode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
     return 0;
 }
 
-int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32_t n,
-                       uint8_t* out, const uint64_t* out_off, int32_t* err,
-                       uint64_t start_bit, uint64_t* end_bit) {
+int decode_host(Lane& c, hipStream_t st, const uint8_t* in, const uint64_t* in_off, uint32_t n,
+                uint8_t* out, const uint64_t* out_off, int32_t* err,
+                uint64_t start_bit, uint64_t* end_bit) {
     const uint64_t in_base = in_off[0], out_base = out_off[0];
     const uint64_t total_in = in_off[n] - in_base, total_out = out_off[n] - out_base;
     std::vector<uint64_t> io(n + 1), oo(n + 1);
@@ -360,7 +402,6 @@ int decode_host_locked(Ctx& c, const uint8_t* in, const uint64_t* in_off, uint32
         (e = c.tokens.reserve((total_out + 64) * 4)) || (e = c.tok_count.reserve((size_t)n * 4))) {
         return e;
     }
-    hipStream_t st = nullptr;
     if (total_in > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in + in_base, total_in, hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipMemcpyAsync(c.in_off.p, io.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c.out_off.p, oo.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -481,13 +522,12 @@ void sqz_compress(struct sqz* s, struct bitstream* bs,
     uint64_t produced = 0;
     int32_t err = 0;
     {
-        Ctx& c = ctx();
-        std::lock_guard<std::mutex> g(c.mu);
-        int e = probe_locked(c);
+        int e = device_ready();
         if (e != 0) { s->error = e; return; }
         // the device writes into a staging slab; it lands behind the header bytes
-        e = encode_host_locked(c, data, in_off, 1, window, dst, out_off, &produced, &err,
-                               bs->b64, bs->bits, &s->tokens);
+        LaneLease lease;
+        e = encode_host(*lease.lane, lease.stream(s->stream), data, in_off, 1, window, dst, out_off, &produced,
+                        &err, bs->b64, bs->bits, &s->tokens);
         if (e != 0) { s->error = e; return; }
     }
     bs->b64 = 0;
@@ -530,7 +570,11 @@ static void decompress_by_callback(struct sqz* s, struct bitstream* bs, uint8_t*
     }
     const uint64_t head_words = buf.size() / 8;
     const uint64_t most_words = head_words + (sqz_bound(bytes) + 16) / 8 + 2;   // no stream of `bytes` bytes is longer
-    uint64_t want_words = head_words + bytes / 32 + 4;   // first guess: a quarter of the size
+    // The reference pulls one word when its bit reader runs dry (bitstream.h:81-85); a device decode wants
+    // its input up front and a word cannot be handed back, so the pull runs AHEAD of the decoder: 4 words,
+    // then twice as many whenever the decoder ran dry.  Words pulled <= max(4, 2 x the words the stream
+    // holds) whatever its compression ratio; every retry decodes again from the stream's start.
+    uint64_t want_words = head_words + 4;
     int src_error = 0;
     bool dry = false;
     for (;;) {
@@ -549,14 +593,16 @@ static void decompress_by_callback(struct sqz* s, struct bitstream* bs, uint8_t*
         int32_t err = 0;
         uint64_t end_bit = 0;
         {
-            Ctx& c = ctx();
-            std::lock_guard<std::mutex> g(c.mu);
-            int e = probe_locked(c);
-            if (e == 0) { e = decode_host_locked(c, buf.data(), in_off, 1, data, out_off, &err, start_bit, &end_bit); }
+            int e = device_ready();
+            if (e == 0) {
+                LaneLease lease;
+                e = decode_host(*lease.lane, lease.stream(s->stream), buf.data(), in_off, 1, data, out_off, &err,
+                                start_bit, &end_bit);
+            }
             if (e != 0) { s->error = e; return; }
         }
         if (err == E2BIG && !dry && limit / 8 < most_words) {   // ran out of words: pull more and decode again
-            want_words = 2 * (limit / 8) + 4;
+            want_words = head_words + 2 * (limit / 8 - head_words);
             continue;
         }
         uint64_t words = 0;
@@ -597,10 +643,12 @@ void sqz_decompress(struct sqz* s, struct bitstream* bs, uint8_t* data, size_t b
     int32_t err = 0;
     uint64_t end_bit = 0;
     {
-        Ctx& c = ctx();
-        std::lock_guard<std::mutex> g(c.mu);
-        int e = probe_locked(c);
-        if (e == 0) { e = decode_host_locked(c, bs->data, in_off, 1, data, out_off, &err, start_bit, &end_bit); }
+        int e = device_ready();
+        if (e == 0) {
+            LaneLease lease;
+            e = decode_host(*lease.lane, lease.stream(s->stream), bs->data, in_off, 1, data, out_off, &err,
+                            start_bit, &end_bit);
+        }
         if (e != 0) { s->error = e; return; }
     }
     uint64_t words = 0;
@@ -618,7 +666,9 @@ static squeeze_type* vt_alloc(uint8_t map_bits) {
     return s;
 }
 static int vt_init_with(squeeze_type* s, void* memory, size_t size, uint8_t map_bits) {
-    if (map_bits != 0 || memory == NULL || s != memory || size != sizeof(squeeze_type)) { return EINVAL; }
+    // squeeze.h:191-199: size == squeeze_sizeof(map_bits).  The codec state lives on the device, so the
+    // caller's block only has to hold the struct; a block sized for the reference's trees is accepted too.
+    if (map_bits != 0 || memory == NULL || s != memory || size < squeeze_sizeof(0)) { return EINVAL; }
     sqz_init(s);
     return 0;
 }
@@ -641,11 +691,11 @@ int sqz_encode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n, uin
         !window_ok(window)) { return EINVAL; }
     if (check_offsets(in_off, n, false) != 0 || check_offsets(out_off, n, true) != 0) { return EINVAL; }
     if (in == NULL && in_off[n] != in_off[0]) { return EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    const int e = probe_locked(c);
+    const int e = device_ready();
     if (e != 0) { return e; }
-    return encode_host_locked(c, in, in_off, n, window, out, out_off, out_bytes, err, 0, 0, nullptr);
+    LaneLease lease;
+    return encode_host(*lease.lane, lease.stream(nullptr), in, in_off, n, window, out, out_off, out_bytes, err,
+                       0, 0, nullptr);
 }
 
 int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
@@ -654,11 +704,10 @@ int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
     if (in == NULL || in_off == NULL || out_off == NULL || err == NULL) { return EINVAL; }
     if (check_offsets(in_off, n, true) != 0 || check_offsets(out_off, n, false) != 0) { return EINVAL; }
     if (out == NULL && out_off[n] != out_off[0]) { return EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    const int e = probe_locked(c);
+    const int e = device_ready();
     if (e != 0) { return e; }
-    return decode_host_locked(c, in, in_off, n, out, out_off, err, 0, nullptr);
+    LaneLease lease;
+    return decode_host(*lease.lane, lease.stream(nullptr), in, in_off, n, out, out_off, err, 0, nullptr);
 }
 
 // ------------------------------------------------------------------ batch, device
@@ -666,12 +715,6 @@ uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes) {
     // token counts + three uint32 slots per input byte (tokens / sort ping-pong, sorted
     // positions, match table)
     return align_up((uint64_t)n * 4, 256) + 3 * (total_in_bytes + 64) * 4;
-}
-
-static int device_ready(void) {
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    return probe_locked(c);
 }
 
 int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
@@ -836,6 +879,7 @@ int sqz_hip_rc_encode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_
         d_err == NULL) { return EINVAL; }
     const int e = device_ready();
     if (e != 0) { return e; }
+    SpanGuard g((hipStream_t)stream, SQZ_HIP_K_RC_ENCODE);
     sqzk::launch_rc_encode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, n,
                            (hipStream_t)stream);
     return hip_errno(hipGetLastError());
@@ -849,21 +893,22 @@ int sqz_hip_rc_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_
         d_err == NULL) { return EINVAL; }
     const int e = device_ready();
     if (e != 0) { return e; }
+    SpanGuard g((hipStream_t)stream, SQZ_HIP_K_RC_DECODE);
     sqzk::launch_rc_decode((const uint8_t*)d_in, d_in_off, (uint8_t*)d_out, d_out_off, d_out_bytes, d_consumed,
-                           d_err, n, (hipStream_t)stream);
+                           d_err, n, 0, (hipStream_t)stream);
     return hip_errno(hipGetLastError());
 }
 
 // one stream through the device, host buffers; returns a HIP-side errno (0 = the kernel ran)
 static int rc_run_host(bool decode, const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_cap,
-                       uint64_t* produced, uint64_t* consumed, int32_t* err) {
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int e = probe_locked(c);
+                       uint64_t* produced, uint64_t* consumed, int32_t* err, int dry_error) {
+    int e = device_ready();
     if (e != 0) { return e; }
+    LaneLease lease;
+    Lane& c = *lease.lane;
+    hipStream_t st = lease.stream(nullptr);
     if ((e = c.in.reserve(in_bytes + 16)) || (e = c.out.reserve(out_cap + 16)) || (e = c.in_off.reserve(16)) ||
         (e = c.out_off.reserve(16)) || (e = c.out_bytes.reserve(16)) || (e = c.err.reserve(8))) { return e; }
-    hipStream_t st = nullptr;
     const uint64_t io[2] = {0, in_bytes}, oo[2] = {0, out_cap};
     if (in_bytes > 0) { HIP_TRY(hipMemcpyAsync(c.in.p, in, in_bytes, hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipMemcpyAsync(c.in_off.p, io, 16, hipMemcpyHostToDevice, st));
@@ -871,7 +916,7 @@ static int rc_run_host(bool decode, const uint8_t* in, uint64_t in_bytes, uint8_
     uint64_t* d_sizes = (uint64_t*)c.out_bytes.p;               // [0] produced, [1] consumed
     if (decode) {
         sqzk::launch_rc_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
-                               (const uint64_t*)c.out_off.p, d_sizes, d_sizes + 1, (int32_t*)c.err.p, 1, st);
+                               (const uint64_t*)c.out_off.p, d_sizes, d_sizes + 1, (int32_t*)c.err.p, 1, dry_error, st);
     } else {
         sqzk::launch_rc_encode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, (uint8_t*)c.out.p,
                                (const uint64_t*)c.out_off.p, d_sizes, (int32_t*)c.err.p, 1, st);
@@ -882,7 +927,10 @@ static int rc_run_host(bool decode, const uint8_t* in, uint64_t in_bytes, uint8_
     HIP_TRY(hipMemcpyAsync(err, c.err.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t got = sizes[0] < out_cap ? sizes[0] : out_cap;
-    if (got > 0) { HIP_TRY(hipMemcpy(out, c.out.p, got, hipMemcpyDeviceToHost)); }
+    if (got > 0) {
+        HIP_TRY(hipMemcpyAsync(out, c.out.p, got, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     *produced = sizes[0];
     if (consumed != NULL) { *consumed = decode ? sizes[1] : 0; }
     return 0;
@@ -895,7 +943,7 @@ void sqz_rc_compress(struct sqz_rc* s, const void* d, size_t b, uint32_t window)
     std::vector<uint8_t> buf(sqz_rc_bound(b));
     uint64_t produced = 0;
     int32_t err = 0;
-    const int e = rc_run_host(false, (const uint8_t*)d, b, buf.data(), buf.size(), &produced, NULL, &err);
+    const int e = rc_run_host(false, (const uint8_t*)d, b, buf.data(), buf.size(), &produced, NULL, &err, 0);
     if (e != 0) { s->rc.error = e; return; }
     if (err != 0) { s->rc.error = err; return; }
     for (uint64_t k = 0; k < produced && s->rc.error == 0; k++) { s->rc.write(&s->rc, buf[k]); }   // rc_emit :474-476
@@ -906,7 +954,11 @@ uint64_t sqz_rc_decompress(struct sqz_rc* s, void* data, size_t bytes) {        
     if ((bytes > 0 && data == NULL) || s->rc.read == NULL || bytes > kMaxStream) { s->rc.error = EINVAL; return 0; }
     std::vector<uint8_t> in;
     const uint64_t most = sqz_rc_bound(bytes) + 64;             // no stream of `bytes` literals is longer
-    uint64_t want = 64;                                         // then twice as much each time the decoder ran dry
+    // The reference reads a byte when its decoder needs one (rc_consume :499-500); a device decode wants its
+    // input up front, so the pull runs AHEAD of the decoder: 64 bytes, then twice as much each time the decoder
+    // ran dry, decoding again from the start.  OVER-READ BOUND: at most max(64, 2 x the bytes the decoder
+    // consumes) are pulled through rc.read (include/sqz/sqz_rc.h).
+    uint64_t want = 64;
     bool dry = false;
     int src_error = 0;
     for (;;) {
@@ -918,13 +970,15 @@ uint64_t sqz_rc_decompress(struct sqz_rc* s, void* data, size_t bytes) {        
         }
         uint64_t produced = 0, consumed = 0;
         int32_t err = 0;
-        const int e = rc_run_host(true, in.data(), in.size(), (uint8_t*)data, bytes, &produced, &consumed, &err);
+        // a source that ended with an error: the decoder's first read past it sets that error, as the
+        // reference's read callback does (test.c:112-121), and the loop ends where the reference's would
+        const int e = rc_run_host(true, in.data(), in.size(), (uint8_t*)data, bytes, &produced, &consumed, &err,
+                                  dry ? src_error : 0);
         if (e != 0) { s->rc.error = e; return 0; }
         if (consumed > in.size() && !dry && in.size() < most) { // ran past what was pulled: pull more, decode again
             want = 2 * in.size();
             continue;
         }
-        if (consumed > in.size() && dry && src_error != 0) { err = src_error; }   // the source ended first: its error
         s->rc.error = err;
         return produced < bytes ? produced : bytes;
     }

@@ -159,8 +159,14 @@ struct RcDecoder {
     const uint8_t* in; uint64_t avail, consumed;
     uint32_t row; uint64_t row_base;          // lane k holds in[row_base + k]
     int error;
+    int dry_error;                            // what a read past the end sets (0: it reads as 0 and that is all)
 
-    __device__ __forceinline__ uint32_t get(int lane) {      // rc.read: bytes past the end read as 0 (test.c:113-122)
+    // rc.read.  Past the end of the stream a byte reads as 0 (test.c:113-122); the reference's own callback
+    // ALSO sets rc.error there when its source failed (test.c:112-121: rc->error = io->error) and the
+    // decoder's loop ends at its next check of it (src/sqz.c:800-802) -- dry_error is that error, handed
+    // in by a caller whose source ended with one (sqz_rc_decompress), so the byte count is the reference's.
+    __device__ __forceinline__ uint32_t get(int lane) {
+        if (dry_error != 0 && consumed >= avail && error == 0) { error = dry_error; }
         if (consumed < row_base || consumed >= row_base + (uint64_t)kWave) {
             row_base = consumed & ~(uint64_t)(kWave - 1);
             row = row_base + (uint64_t)lane < avail ? in[row_base + lane] : 0u;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(kWave)
 void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                       uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
                       uint64_t* __restrict__ out_bytes, uint64_t* __restrict__ consumed_out,
-                      int32_t* __restrict__ err_out, uint32_t n_blocks) {
+                      int32_t* __restrict__ err_out, uint32_t n_blocks, int dry_error) {
     __shared__ RcLds lds;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -213,7 +219,7 @@ void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict
     uint8_t* d = out + uni64(out_off[b]);
     const uint64_t cap = uni64(out_off[b + 1]) - uni64(out_off[b]);
     RcDecoder rc;
-    rc.low = 0; rc.range = ~0ull; rc.code = 0; rc.error = 0;
+    rc.low = 0; rc.range = ~0ull; rc.code = 0; rc.error = 0; rc.dry_error = dry_error;
     rc.in = in + uni64(in_off[b]); rc.avail = uni64(in_off[b + 1]) - uni64(in_off[b]);
     rc.consumed = 0; rc.row_base = ~0ull; rc.row = 0;
     for (int k = 0; k < 8; k++) { rc.code = (rc.code << 8) + rc.get(lane); }             // :794-797
@@ -272,13 +278,10 @@ void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict
                     else if (n <= cap) {                                                 // :826-830 byte-serial, overlap allowed
                         flush();
                         __threadfence_block();
-                        if (lane == 0) {
-                            for (uint64_t k = i; k < n; k++) {
-                                d[k] = __hip_atomic_load(d + k - dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __threadfence_block();
-                            }
+                        for (uint64_t k = i; k < n; k++) {                               // (the wave stays uniform: every lane fences)
+                            if (lane == 0) { d[k] = __hip_atomic_load(d + k - dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            __threadfence_block();
                         }
-                        __threadfence_block();
                         i = n;
                     } else { rc.error = kRcENOBUFS; }
                 }
@@ -300,9 +303,11 @@ void launch_rc_encode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, c
 }
 
 void launch_rc_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
-                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, hipStream_t stream) {
+                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, int dry_error,
+                      hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(rc_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream, in, in_off, out, out_off, out_bytes, consumed, err, n_blocks);
+    hipLaunchKernelGGL(rc_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream, in, in_off, out, out_off, out_bytes, consumed, err,
+                       n_blocks, dry_error);
 }
 
 } // namespace sqzk

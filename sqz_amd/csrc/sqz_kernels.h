@@ -59,7 +59,8 @@ void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t
 void launch_rc_encode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
                       uint64_t* out_bytes, int32_t* err, uint32_t n_blocks, hipStream_t stream);
 void launch_rc_decode(const uint8_t* in, const uint64_t* in_off, uint8_t* out, const uint64_t* out_off,
-                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, hipStream_t stream);
+                      uint64_t* out_bytes, uint64_t* consumed, int32_t* err, uint32_t n_blocks, int dry_error,
+                      hipStream_t stream);
 
 // slabs -> dense image of a batch's streams (blocks.hip): block b moves from src + src_off[b]
 // to dst + dst_off[b].  bytes[b] and all offsets are multiples of 8.

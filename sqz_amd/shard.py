@@ -125,6 +125,14 @@ def max_over_ranks(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: float, device, group=None) -> float:
+    """all ranks agree on the smallest value: an ok flag (1.0 / 0.0) after a phase that may fail on one
+    rank alone, so that every rank takes or skips the next collective TOGETHER"""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return float(t.item())
+
+
 def sum_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

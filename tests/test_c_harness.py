@@ -11,6 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "harness", "sqz_harness.c")
 EXE = os.path.join(ROOT, "tests", "harness", "sqz_harness")
+SRC_B = os.path.join(ROOT, "tests", "harness", "sqz_boundary.c")
+EXE_B = os.path.join(ROOT, "tests", "harness", "sqz_boundary")
 
 
 @pytest.fixture(scope="module")
@@ -22,6 +24,36 @@ def harness():
                            "-I" + os.path.join(ROOT, "include"), SRC, "-L" + libdir, "-lsqz_amd",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE])
     return EXE
+
+
+@pytest.fixture(scope="module")
+def boundary():
+    from sqz_amd import build
+    build.build_native()
+    libdir = os.path.join(ROOT, "sqz_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror",
+                           "-I" + os.path.join(ROOT, "include"), SRC_B, "-L" + libdir, "-lsqz_amd", "-lpthread",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE_B])
+    return EXE_B
+
+
+def test_boundary_names_compile_and_are_loud_without_gpu(boundary):
+    """squeeze_* constants / squeeze_sizeof of squeeze.h:9-25,94-107 compile as C99 (static asserts on
+    their values inside the program); without a device the program reports ENODEV"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([boundary], cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode == errno.ENODEV and "no gfx950 device" in p.stdout
+
+
+@pytest.mark.gpu
+def test_boundary_trailer_init_with_and_two_threads(boundary, tmp_path):
+    """a stream followed by other data through `.input` (bs.read = the reference's figure, the shim's
+    over-read within its documented bound), init_with on a caller block of squeeze_sizeof(0) bytes,
+    two threads compressing at once"""
+    p = subprocess.run([boundary], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1] == "ok", p.stdout + p.stderr
 
 
 def test_harness_is_c99_and_loud_without_gpu(harness):

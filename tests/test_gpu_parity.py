@@ -239,6 +239,20 @@ def test_full_size_roundtrip_properties(sq, batch):
     torch.cuda.synchronize()
     assert int(derr.abs().sum()) == 0
     assert torch.equal(d_back, d_in)
+    # Stage 1 pinned on ALL 4096 blocks: the brute-force scan (squeeze.h:338-358 as written, itself held
+    # against the oracle token for token in test_tokens_vs_oracle) and the indexed finder the bench runs must
+    # produce the same token words for every block of the benchmark batch -- the bst.c:254-308 differential
+    # pattern at full size.  (The fingerprints above pin 42 streams end to end; this pins every parse.)
+    del d_back, dense
+    t_idx, c_idx = enc.tokens(d_in, off, 1 << 15, finder="index")
+    t_scan, c_scan = enc.tokens(d_in, off, 1 << 15, finder="scan")
+    torch.cuda.synchronize()
+    assert torch.equal(c_idx, c_scan) and int(c_idx.min()) > 150000
+    # block b's words are tokens[b * bb .. + count[b]): compare only the written part of every block
+    pos = torch.arange(n * bb, device="cuda", dtype=torch.int64)
+    live = (pos % bb) < c_idx.to(torch.int64).repeat_interleave(bb)
+    del pos
+    assert torch.equal(t_idx[:n * bb][live], t_scan[:n * bb][live])
 
 
 # ---------------------------------------------------------------- API shapes / errors

@@ -134,6 +134,126 @@ def test_kernels_on_the_wave_emulator():
         assert (int(derr[b]), dec[int(d_off[b]):int(d_off[b]) + int(db[b])].tobytes(), int(cons[b])) == (eo, bo, co), b
 
 
+
+# ---- the decoder's back-reference branch (src/sqz.c:809-833): streams no encoder of the reference writes ----
+def _token_cases():
+    """(name, tokens, capacity): token sequences written by tests/rc_token_encoder.py (test-only encoder with
+    HEAD's models and arithmetic).  Covers: plain and overlapping copies (dist < size: RLE), the longest size,
+    distances through many bit models, a copy reaching before the start (ERANGE, :824), a copy running past
+    the caller's buffer (ENOBUFS, :832), sizes outside 2..254 (ERANGE, :810), a literal into a full buffer."""
+    import rc_token_encoder as R
+    rng = random.Random(11)
+    text = [("lit", b) for b in b"the quick brown fox jumps over the lazy dog. "]
+    cases = []
+    cases.append(("copies", text + [("match", 9, 5, 12), ("match", 5, 2, 1), ("lit", 33), ("match", 254, 1, 0),
+                                     ("match", 2, 4, 7), ("lit", 10)], None))
+    cases.append(("rle", [("lit", 65), ("lit", 66), ("match", 200, 1, 0), ("match", 17, 1, 0), ("lit", 67)], None))
+    long = [("lit", rng.randrange(256)) for _ in range(5000)]
+    for _ in range(300):
+        bits = rng.randint(1, 12)
+        low = rng.randrange(1 << (bits - 1)) if bits > 1 else 0
+        long.append(("match", rng.randint(2, 254), bits, low) if rng.random() < 0.5 else ("lit", rng.randrange(256)))
+    cases.append(("long", long, None))
+    cases.append(("before_start", text[:5] + [("match", 4, 3, 2), ("lit", 1)], None))            # dist 10 > i = 5
+    cases.append(("past_buffer", text + [("match", 100, 2, 0)], len(text) + 50))                  # n > capacity
+    cases.append(("size_0", text[:9] + [("match", 0, 0, 0), ("lit", 2)], None))
+    cases.append(("size_1", text[:9] + [("match", 1, 0, 0), ("lit", 2)], None))
+    cases.append(("full_literal", text, len(text) - 1))
+    out = []
+    for name, toks, cap in cases:
+        good = []
+        for t in toks:                                   # what a decoder writes before the first refused token
+            if t[0] == "match" and (t[1] < 2 or t[1] > 254 or R.distance(t[2], t[3]) > len(R.expand(good))):
+                break
+            good.append(t)
+        out.append((name, R.encode_tokens(toks), cap if cap is not None else len(R.expand(good)) + 40))
+    return out
+
+
+def _ref_decode_dry(stream, cap, dry):
+    REF.sqz_ref_rc_decompress_dry.restype = C.c_int
+    back = C.create_string_buffer(max(cap, 1))
+    got, cons = C.c_uint64(), C.c_uint64()
+    e = REF.sqz_ref_rc_decompress_dry(stream, C.c_uint64(len(stream)), back, C.c_uint64(cap), C.byref(got), C.byref(cons),
+                                      C.c_int(dry))
+    return e, back.raw[:got.value], cons.value
+
+
+def _ora_decode_dry(stream, cap, dry):
+    out = C.create_string_buffer(max(cap, 1))
+    n, cons = C.c_uint64(), C.c_uint64()
+    e = O.ORACLE.sqzo_rc_decode_dry(stream, C.c_uint64(len(stream)), out, C.c_uint64(cap), C.byref(n), C.byref(cons), C.c_int(dry))
+    return e, out.raw[:n.value], cons.value
+
+
+def _dry_cases():
+    """valid and token streams cut short, read from a source that FAILS at its end (errno 5): the byte count
+    is what the reference returns when its read callback reports the failure (test.c:112-121)"""
+    cases = _token_cases()
+    d = O.corpus("laozi.txt")[:3000]
+    s = ora_encode(d)[1]
+    cuts = [(s[:k], len(d) + 10) for k in (0, 5, 8, 9, 100, 1500, len(s) - 9, len(s) - 1, len(s))]
+    cuts += [(st[:len(st) * 2 // 3], cap) for _, st, cap in cases[:3]]
+    return cuts
+
+
+def test_back_reference_branch_on_the_oracle_and_the_reference():
+    import rc_token_encoder as R
+    for name, stream, cap in _token_cases():
+        eo, bo, co = ora_decode(stream, cap)
+        if name in ("copies", "rle", "long"):
+            assert eo == 0 and co == len(stream), name
+        elif name in ("before_start", "size_0", "size_1"):
+            assert eo == errno.ERANGE, name
+        else:
+            assert eo == errno.ENOBUFS, name
+        if REF is not None:
+            back = C.create_string_buffer(max(cap, 1))
+            got, cons = C.c_uint64(), C.c_uint64()
+            er = REF.sqz_ref_rc_decompress(stream, C.c_uint64(len(stream)), back, C.c_uint64(cap), C.byref(got), C.byref(cons))
+            assert (er, back.raw[:got.value], cons.value) == (eo, bo, co), name
+    # the test encoder against itself: literal-only streams are the oracle's encoder's
+    d = O.zipf_block(3, 2000)
+    assert R.encode_tokens([("lit", b) for b in d]) == ora_encode(d)[1]
+    toks = [("lit", 7), ("lit", 8), ("match", 10, 1, 0)]
+    assert ora_decode(R.encode_tokens(toks), 12)[1] == R.expand(toks) == bytes([7, 8] * 6)
+    for stream, cap in _dry_cases():
+        eo, bo, co = _ora_decode_dry(stream, cap, 5)
+        if REF is not None:
+            assert _ref_decode_dry(stream, cap, 5) == (eo, bo, co)
+
+
+def test_back_reference_branch_on_the_wave_emulator():
+    import test_emu as TE
+    TE.VARIANTS.setdefault("default", [])
+    E = TE._build("default", "rc")
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(streams, caps, dry):
+        m = len(streams)
+        s_off = np.zeros(m + 1, np.uint64)
+        s_off[1:] = np.cumsum([len(s) for s in streams])
+        sd = np.frombuffer(b"".join(streams) + b"\0" * 8, np.uint8).copy()
+        d_off = np.zeros(m + 1, np.uint64)
+        d_off[1:] = np.cumsum(caps)
+        dec = np.zeros(int(d_off[-1]) + 8, np.uint8)
+        db, cons, derr = np.zeros(m, np.uint64), np.zeros(m, np.uint64), np.zeros(m, np.int32)
+        if dry:
+            E.emu_rc_decode_dry(p(sd), p(s_off), m, p(dec), p(d_off), p(db), p(cons), p(derr), dry)
+        else:
+            E.emu_rc_decode(p(sd), p(s_off), m, p(dec), p(d_off), p(db), p(cons), p(derr))
+        return [(int(derr[b]), dec[int(d_off[b]):int(d_off[b]) + int(db[b])].tobytes(), int(cons[b])) for b in range(m)]
+
+    cases = _token_cases()
+    got = run([c[1] for c in cases], [c[2] for c in cases], 0)
+    for (name, stream, cap), g in zip(cases, got):
+        assert g == ora_decode(stream, cap), name
+    dry = _dry_cases()
+    got = run([c[0] for c in dry], [c[1] for c in dry], 5)
+    for k, ((stream, cap), g) in enumerate(zip(dry, got)):
+        assert g == _ora_decode_dry(stream, cap, 5), k
+
+
 def test_heads_caller_compiles_against_the_header(tmp_path):
     """shl.c:13-68's flow (put / get over a static buffer, sqz_init, rc.write / rc.read, sqz_compress,
     sqz_decompress) written against <sqz/sqz_rc.h> with the reference's own names"""
@@ -291,3 +411,58 @@ def test_gpu_batch_device_resident():
         assert got == ora_encode(O.zipf_block(b, bb))[1]
         if b in z:
             assert (len(got), O.fnv(got)) == (z[b]["out_bytes"], z[b]["out_fnv"])
+
+
+@pytest.mark.gpu
+def test_gpu_back_reference_branch_and_dry_sources():
+    """the decoder's back-reference branch (src/sqz.c:809-833) on the device, on streams written by the test-only
+    token encoder: errno, bytes and consumption equal the oracle's (which equals the compiled reference's, CPU
+    tests); then through rc.read with a source that fails at its end: the byte count sqz_rc_decompress returns"""
+    import torch
+    from sqz_amd import _native as N
+    from sqz_amd import batch
+    L = N.lib()
+    cases = _token_cases()
+    m = len(cases)
+    streams, caps = [c[1] for c in cases], [c[2] for c in cases]
+    s_off = np.zeros(m + 1, np.int64)
+    s_off[1:] = np.cumsum([len(s) for s in streams])
+    d_off = np.zeros(m + 1, np.int64)
+    d_off[1:] = np.cumsum(caps)
+    dev = "cuda"
+    sd = torch.tensor(np.frombuffer(b"".join(streams) + b"\0" * 8, np.uint8).copy(), device=dev)
+    dec = torch.zeros(int(d_off[-1]) + 8, dtype=torch.uint8, device=dev)
+    t_s, t_d = torch.tensor(s_off, device=dev), torch.tensor(d_off, device=dev)
+    db = torch.zeros(m, dtype=torch.int64, device=dev)
+    cons = torch.zeros(m, dtype=torch.int64, device=dev)
+    derr = torch.zeros(m, dtype=torch.int32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert L.sqz_hip_rc_decode_blocks(P(sd), P(t_s), m, P(dec), P(t_d), P(db), P(cons), P(derr), None) == 0
+    torch.cuda.synchronize()
+    h = dec.cpu().numpy()
+    for b, (name, stream, cap) in enumerate(cases):
+        got = (int(derr[b]), h[int(d_off[b]):int(d_off[b]) + int(db[b])].tobytes(), int(cons[b]))
+        assert got == ora_decode(stream, cap), name
+
+    def gpu_decode_failing_source(stream, cap):
+        pos = [0]
+
+        @N.RC_READ
+        def get(rc):
+            if pos[0] >= len(stream):
+                rc.contents.error = 5                 # the source failed (EIO): test.c:112-121
+                return 0
+            v = stream[pos[0]]
+            pos[0] += 1
+            return v
+
+        s = N.SqzRc()
+        L.sqz_rc_init(C.byref(s), None, 0)
+        s.rc.read = get
+        out = C.create_string_buffer(max(cap, 1))
+        n = L.sqz_rc_decompress(C.byref(s), out, cap)
+        return s.rc.error, out.raw[:n]
+
+    for k, (stream, cap) in enumerate(_dry_cases()):
+        eo, bo, _ = _ora_decode_dry(stream, cap, 5)
+        assert gpu_decode_failing_source(stream, cap) == (eo, bo), k

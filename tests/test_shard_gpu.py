@@ -70,7 +70,17 @@ def test_scatter_hip_encode_gather_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    streams, total, derr, same = q.get()        # before the joins: a full pipe would block rank 0's put
+    # rank 0's result is read BEFORE the joins (a full pipe would block its put) -- but by polling: a
+    # worker that dies before its put must fail the test with its exit code, not block it for ever
+    import time
+    deadline = time.time() + 540
+    while q.empty():
+        dead = [(r, p.exitcode) for r, p in enumerate(procs) if not p.is_alive() and p.exitcode != 0]
+        assert not dead, f"worker(s) exited without a result: (rank, exit code) {dead}"
+        assert any(p.is_alive() for p in procs) or not q.empty(), "workers exited cleanly without a result"
+        assert time.time() < deadline, "no result from rank 0 within 540 s"
+        time.sleep(0.2)
+    streams, total, derr, same = q.get()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
