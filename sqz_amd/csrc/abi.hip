@@ -282,7 +282,8 @@ int finder_default() {
 }
 
 uint32_t match_groups_for(uint64_t avg_block_bytes) {
-    uint64_t g = (avg_block_bytes + 1023) / 1024;
+    static const int div = [] { const char* e = getenv("SQZ_MATCH_DIV"); const int v = e != NULL ? atoi(e) : 1024; return v >= 256 ? v : 1024; }();
+    uint64_t g = (avg_block_bytes + div - 1) / div;
     if (g < 1) { g = 1; }
     if (g > 65535) { g = 65535; }
     return (uint32_t)g;

@@ -284,15 +284,42 @@ void index_match_kernel(const uint8_t* __restrict__ in,
     uint32_t* M = match + in_off[b];
 
     const int lane = (int)(threadIdx.x & (kWave - 1));
-    for (uint32_t r0 = group * blockDim.x + (threadIdx.x - (uint32_t)lane); r0 < count; r0 += groups * blockDim.x) {
+    // A wave owns a CONTIGUOUS run of pages (a page = 64 consecutive ranks), so that the page it has just
+    // finished is still in its registers when the next one looks back across the page's first rank.
+    const uint32_t pages = (count + (uint32_t)kWave - 1u) / (uint32_t)kWave;
+    const uint32_t waves = groups * (blockDim.x / (uint32_t)kWave);
+    const uint32_t per_wave = (pages + waves - 1u) / waves;
+    const uint32_t wave_id = group * (blockDim.x / (uint32_t)kWave) + (threadIdx.x - (uint32_t)lane) / (uint32_t)kWave;
+    const uint32_t page_lo = wave_id * per_wave;
+    const uint32_t page_hi = page_lo + per_wave < pages ? page_lo + per_wave : pages;
+    // a position's first 16 bytes (zeros beyond the stream's end: never compared, lengths stop at cap <= n - i)
+    auto load16 = [&](uint32_t at, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+        if (at + 16 <= n) {
+            w0 = load_u32_unaligned(src + at); w1 = load_u32_unaligned(src + at + 4);
+            w2 = load_u32_unaligned(src + at + 8); w3 = load_u32_unaligned(src + at + 12);
+        } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < 16 && at + k < n; k++) { w[k >> 2] |= (uint32_t)src[at + k] << (8 * (k & 3)); }
+            w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+        }
+    };
+    // the page in front of the current one: positions and their first 8 bytes (lane = rank inside the page)
+    uint32_t prev_i = 0, prev0 = 0, prev1 = 0, prev2 = 0, prev3 = 0;
+    if (page_lo > 0 && page_lo < page_hi) {                  // (every rank of an earlier page exists)
+        prev_i = S[(page_lo - 1u) * (uint32_t)kWave + (uint32_t)lane];
+        load16(prev_i, prev0, prev1, prev2, prev3);
+    }
+    for (uint32_t pg = page_lo; pg < page_hi; pg++) {
+        const uint32_t r0 = pg * (uint32_t)kWave;
+        const bool have_prev = pg > 0;
         const uint32_t r = r0 + (uint32_t)lane;              // a wave owns 64 consecutive ranks
         const bool valid = r < count;
         const uint32_t i = valid ? S[r] : 0u;
         const uint32_t cap = (n - i) < (uint32_t)kLenMax ? (n - i) : (uint32_t)kLenMax;
         const uint32_t reach = i < window - 1 ? i : window - 1;
-        // i <= n-3; a 4-byte load may touch byte i+3 == n only for the last position
-        const uint32_t key = (i + 4 <= n) ? (load_u32_unaligned(src + i) & 0x00FFFFFFu)
-            : ((uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16));
+        uint32_t own0 = 0, own1 = 0, own2 = 0, own3 = 0;
+        if (valid) { load16(i, own0, own1, own2, own3); }
+        const uint32_t key = own0 & 0x00FFFFFFu;             // i <= n - 3: the key's bytes are the stream's
         uint32_t best = 0, dist = 0;
         // one lane on its own: the candidates of ranks q_from-1, q_from-2, ... (nearest first)
         auto walk = [&](uint32_t q_from) {
@@ -325,8 +352,6 @@ void index_match_kernel(const uint8_t* __restrict__ in,
             // position comes from a register page of sorted positions (v_readlane), its bytes from
             // one broadcast load, and every lane compares them with its own first 16 bytes, held in
             // registers -- no per-lane gathers.  Same order (nearest first), same strict >.
-            const uint32_t own0 = load_u32_unaligned(src + i), own1 = load_u32_unaligned(src + i + 4);
-            const uint32_t own2 = load_u32_unaligned(src + i + 8), own3 = load_u32_unaligned(src + i + 12);
             bool done = false, deferred = false;
             uint32_t resume = 0;
             uint32_t page_base = r0, page = i;               // page = sorted positions of ranks [page_base, +64)
@@ -378,11 +403,77 @@ void index_match_kernel(const uint8_t* __restrict__ in,
             }
             if (deferred) { walk(resume); }
             M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : (key & 0xFFu);   // no match: the literal itself
+            prev_i = i; prev0 = own0; prev1 = own1; prev2 = own2; prev3 = own3;
             continue;
         }
-        if (!valid) { continue; }
-        walk(r);
-        M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : (key & 0xFFu);   // no match: the literal itself
+        // ---- several runs in one wave (the usual case: 2.7 candidates per position on Zipf bytes) ------
+        // The candidates of rank r are the ranks r-1, r-2, ... of its run, nearest first -- and those are
+        // the positions the NEIGHBOURING LANES hold, in this page or in the one before it (kept from the
+        // previous turn of the loop).  A candidate's position and bytes come out of lane l-k's registers
+        // through the LDS crossbar (ds_bpermute): no gather and no dependent load per candidate (a lane that
+        // walks by itself pays three dependent global loads per candidate, and one such lane holds up its
+        // wave: with per-lane walks the kernel ran at 13 us per page).  Same order, same strict >.  What the
+        // registers cannot settle leaves the loop and is finished by the lane itself with walk(): a match
+        // longer than the 16 bytes held, and a run that reaches back more than 64 ranks.
+        bool done = !valid;
+        bool later = false;                                      // this lane finishes by itself, from rank `resume` down
+        uint32_t resume = 0;
+        for (int k = 1; k <= kWave; k++) {
+            const int from = lane - k;
+            const bool in_cur = from >= 0;
+            if (!done && !in_cur && !have_prev) { done = true; }  // nothing lies in front of rank 0
+            if (__ballot(!done) == 0) { break; }
+            const int addr = (from & (kWave - 1)) << 2;
+            uint32_t pc = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)i);
+            uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)own0);
+            uint32_t c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)own1);
+            const bool back = __ballot(!done && !in_cur) != 0;   // someone looks into the page before
+            if (back) {
+                const uint32_t qc = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)prev_i);
+                const uint32_t q0 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)prev0);
+                const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)prev1);
+                pc = in_cur ? pc : qc; c0 = in_cur ? c0 : q0; c1 = in_cur ? c1 : q1;
+            }
+            const uint32_t x0 = own0 ^ c0, x1 = own1 ^ c1;
+            if (!done && (x0 & 0x00FFFFFFu) != 0) { done = true; }           // left the run: so have all earlier ranks
+            const uint32_t d = i - pc;
+            if (!done && d > reach) { done = true; }                        // everything further is farther
+            uint32_t len = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
+            if (__ballot(!done && len == 8u && cap > 8u) != 0) {             // (rare on Zipf bytes: the other two words)
+                uint32_t c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)own2);
+                uint32_t c3 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)own3);
+                if (back) {
+                    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)prev2);
+                    const uint32_t q3 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)prev3);
+                    c2 = in_cur ? c2 : q2; c3 = in_cur ? c3 : q3;
+                }
+                const uint32_t x2 = own2 ^ c2, x3 = own3 ^ c3;
+                if (len == 8u) {
+                    len = x2 != 0 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : x3 != 0 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+                }
+            }
+            if (!done) {
+                if (len == 16u && cap > 16u) {                   // longer than the registers hold: this lane goes on
+                    later = true;                                // by itself, starting with this very candidate
+                    resume = r - (uint32_t)k + 1u;
+                    done = true;
+                } else {
+                    if (len > cap) { len = cap; }
+                    if (len > best) {                            // strictly longer: nearest among equals
+                        best = len; dist = d;
+                        if (best >= cap) { done = true; }
+                    }
+                    if (!done && k == kWave) {                   // 64 ranks back and still inside the run
+                        later = true;
+                        resume = r - (uint32_t)kWave;
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (later) { walk(resume); }
+        if (valid) { M[i] = best >= (uint32_t)kLenMin ? ((best << 16) | dist) : (key & 0xFFu); }   // no match: the literal itself
+        prev_i = i; prev0 = own0; prev1 = own1; prev2 = own2; prev3 = own3;
     }
 }
 

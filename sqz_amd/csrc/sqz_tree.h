@@ -1137,19 +1137,58 @@ template <bool kWantCode, class LIT, class POS>
 __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, const LIT& lit, const POS& pos,
                                           int lane, int m, int a, int b,
                                           uint32_t& code_a, int& depth_a, uint32_t& code_b, int& depth_b) {
+    // LATENCY.  One wave alone on its SIMD pays ~100 cycles for every LDS round trip it WAITS for, and a
+    // step used to wait for two dozen of them one after the other (every node's probe was its own chain of
+    // three dependent reads, each behind a branch: 3.5 k cycles).  The reads of a step depend on each other
+    // in only three levels -- (1) a node's range word and count, (2) its partner's count and the range words
+    // of its first and last leaf, (3) the prefix sums at its two ends -- so all probes go through the levels
+    // TOGETHER, branch-free on clamped indices (a lane without a node reads the root's words and is masked
+    // out at the end): three round trips with 16-20 reads in flight each, and the histogram's own chain
+    // (zero, add, read, scan, write) runs while the level-2 reads are on their way.
     SEC_BEGIN
     const bool take = lane < m;
     const bool has_a = take && a >= 0, has_b = take && b >= 0;
     const int ia = has_a ? a : LIT::kRoot - 1, ib = has_b ? b : POS::kRoot - 1;      // (idle lanes look at a pad leaf)
+    constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
+    constexpr int kRows = kLitRows + 1;                                         // + the distance tree's row
+    // ---- level 1: range word and count of the tokens' leaves and of this lane's internal nodes ----------
+    int vi[kRows];
+    bool on[kRows];
+#pragma unroll
+    for (int row = 0; row < kLitRows; row++) {
+        const int v = LIT::kRoot + row * kWave + lane;
+        on[row] = v < lit.next && v != LIT::kRoot;
+        vi[row] = on[row] ? v : LIT::kRoot;
+    }
+    {
+        const int v = POS::kRoot + lane;
+        on[kLitRows] = v < pos.next && v != POS::kRoot;
+        vi[kLitRows] = on[kLitRows] ? v : POS::kRoot;
+    }
     const uint32_t ra = lds->rng[ia], rb = lds->rng[ib];
-    const uint32_t qa = r_pos(ra), qb = r_pos(rb);
     const uint32_t wa = lds->cnt[ia], wb = lds->cnt[ib];
-    depth_a = (int)c_d(wa);
-    depth_b = (int)c_d(wb);
+    uint32_t rw[kRows], cw[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) { rw[k] = lds->rng[vi[k]]; cw[k] = lds->cnt[vi[k]]; }
     if (kWantCode) {
         code_a = code[has_a ? ia - LIT::kBase + 0 : 0];
         code_b = code[has_b ? ib - POS::kBase + kPosPos0 : 0];
     }
+    const uint32_t qa = r_pos(ra), qb = r_pos(rb);
+    depth_a = (int)c_d(wa);
+    depth_b = (int)c_d(wb);
+    // ---- level 2: partners' counts, the ends' positions (on their way while the histogram is made) -------
+    const uint32_t pa_a = r_pa(ra), pa_b = r_pa(rb);
+    const uint32_t cpa = lds->cnt[pa_a != kNil ? pa_a : (uint32_t)ia], cpb = lds->cnt[pa_b != kNil ? pa_b : (uint32_t)ib];
+    uint32_t cp[kRows], rf[kRows], rl[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+        const uint32_t pk = r_pa(rw[k]);
+        cp[k] = lds->cnt[pk != kNil ? pk : (uint32_t)vi[k]];
+        rf[k] = lds->rng[r_first(rw[k])];
+        rl[k] = lds->rng[r_last(rw[k])];
+    }
+    SEC(0)
     // ---- histogram over positions (a byte each), then its prefix sums in place ----------------
     auto histogram = [&](int upto) {
         lds->P64[lane] = 0ull;
@@ -1166,67 +1205,43 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
         lds->P64[lane] = (incl << 8) + (uint64_t)base * 0x0101010101010101ull;     // exclusive: P[i] = symbols at positions < i
         lds_fence();
     };
-    // how many of the batch's chains pass node v, and the node's test: f + n <= count of its partner
-    struct Probe { uint32_t st, en, n, f, fb; bool tested; };
-    auto probe = [&](int v, bool leaf, bool on) {
-        Probe r;
-        const uint32_t w = lds->rng[v];
-        const uint32_t pa = r_pa(w);
-        const uint32_t cv = lds->cnt[v], cp = lds->cnt[pa != kNil ? pa : (uint32_t)v];
-        if (leaf) {
-            r.st = r_pos(w); r.en = r.st + 1u;
-        } else {
-            r.st = r_pos(lds->rng[r_first(w)]);
-            r.en = r_pos(lds->rng[r_last(w)]) + 1u;
-        }
-        r.n = on ? (uint32_t)lds->P8[r.en] - (uint32_t)lds->P8[r.st] : 0u;
-        r.tested = r.n != 0 && pa != kNil;
-        r.f = c_f(cv);
-        r.fb = c_f(cp);
-        return r;
-    };
-    SEC(0)
     histogram(m);
     SEC(1)
-    // ---- every touched node's test: the tokens' own leaves (duplicates test the same node twice:
-    //      harmless), then the internal nodes, one lane per node ------------------------------------
-    constexpr int kLitRows = (kLitNodes - kLitLeaves + kWave - 1) / kWave;      // 5
+    // ---- level 3: how many of the batch's chains pass each node (its position run in the prefix sums) ---
+    uint32_t st[kRows], en[kRows], pst[kRows], pen[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) { st[k] = r_pos(rf[k]); en[k] = r_pos(rl[k]) + 1u; }
+    const uint32_t p_a0 = lds->P8[qa], p_a1 = lds->P8[qa + 1u], p_b0 = lds->P8[qb], p_b1 = lds->P8[qb + 1u];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) { pst[k] = lds->P8[st[k]]; pen[k] = lds->P8[en[k]]; }
+    // ---- every touched node's test: f + n <= count of its partner (a lo child's sibling, a hi child's
+    //      uncle); the tokens' own leaves first (duplicates test the same node twice: harmless) -------------
     // per tested node, kept in a register: its position run and how many chains may still pass it
     // (st | en << 9 | min(partner's count - its count, 255) << 18)
-    auto pack = [](const Probe& r) {
-        const uint32_t allowed = r.fb > r.f ? r.fb - r.f : 0u;
-        return r.st | (r.en << 9) | ((allowed < 255u ? allowed : 255u) << 18);
+    auto pack = [](uint32_t s0, uint32_t e0, uint32_t f, uint32_t fb) {
+        const uint32_t allowed = fb > f ? fb - f : 0u;
+        return s0 | (e0 << 9) | ((allowed < 255u ? allowed : 255u) << 18);
     };
     uint32_t nl[kLitRows], sel[kLitRows], np = 0, sep = 0;     // per row: chains through my node, its packed test
     uint32_t bad = 0;                                   // bit 0 / 1: my leaves; bit 2 + r: my node of lit row r; bit 7: pos row
     uint32_t sa, sb;
     {
-        const Probe r = probe(ia, true, has_a);
-        sa = pack(r);
-        bad |= (r.tested && r.f + r.n > r.fb) ? 1u : 0u;
+        const uint32_t n = has_a ? p_a1 - p_a0 : 0u, f = c_f(wa), fb = c_f(cpa);
+        sa = pack(qa, qa + 1u, f, fb);
+        bad |= (n != 0 && pa_a != kNil && f + n > fb) ? 1u : 0u;
     }
     {
-        const Probe r = probe(ib, true, has_b);
-        sb = pack(r);
-        bad |= (r.tested && r.f + r.n > r.fb) ? 2u : 0u;
+        const uint32_t n = has_b ? p_b1 - p_b0 : 0u, f = c_f(wb), fb = c_f(cpb);
+        sb = pack(qb, qb + 1u, f, fb);
+        bad |= (n != 0 && pa_b != kNil && f + n > fb) ? 2u : 0u;
     }
 #pragma unroll
-    for (int row = 0; row < kLitRows; row++) {
-        const int v = LIT::kRoot + row * kWave + lane;
-        nl[row] = 0; sel[row] = 0;
-        if (LIT::kRoot + row * kWave < lit.next) {
-            const bool on = v < lit.next && v != LIT::kRoot;
-            const Probe r = probe(on ? v : LIT::kRoot, false, on);
-            nl[row] = r.n; sel[row] = on ? pack(r) : 0u;
-            bad |= (r.tested && r.f + r.n > r.fb) ? (4u << row) : 0u;
-        }
-    }
-    {
-        const int v = POS::kRoot + lane;
-        const bool on = v < pos.next && v != POS::kRoot;
-        const Probe r = probe(on ? v : POS::kRoot, false, on);
-        np = r.n; sep = on ? pack(r) : 0u;
-        bad |= (r.tested && r.f + r.n > r.fb) ? 128u : 0u;
+    for (int k = 0; k < kRows; k++) {
+        const uint32_t n = on[k] ? pen[k] - pst[k] : 0u, f = c_f(cw[k]), fb = c_f(cp[k]);
+        const uint32_t packed = on[k] ? pack(st[k], en[k], f, fb) : 0u;
+        const bool fails = n != 0 && r_pa(rw[k]) != kNil && f + n > fb;
+        if (k < kLitRows) { nl[k] = n; sel[k] = packed; bad |= fails ? (4u << k) : 0u; }
+        else { np = n; sep = packed; bad |= fails ? 128u : 0u; }
     }
     int ok = m;
     SEC(2)
@@ -1243,8 +1258,8 @@ __device__ __forceinline__ int bump_batch(TreeLds* lds, const uint32_t* code, co
                 const int k = __builtin_ctzll(vm);
                 vm &= vm - 1;
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
-                const uint32_t st = t & 0x1FFu, en = (t >> 9) & 0x1FFu, allowed = t >> 18;
-                const bool through = (has_a && qa >= st && qa < en) || (has_b && qb >= st && qb < en);
+                const uint32_t s0 = t & 0x1FFu, e0 = (t >> 9) & 0x1FFu, allowed = t >> 18;
+                const bool through = (has_a && qa >= s0 && qa < e0) || (has_b && qb >= s0 && qb < e0);
                 const uint64_t tm = __ballot(through);
                 const uint64_t first_bad = __ballot(through && lanes_under(tm) == allowed);
                 if (first_bad != 0) { const int j = __builtin_ctzll(first_bad); ok = j < ok ? j : ok; }
