@@ -281,6 +281,19 @@ int finder_default() {
     return f;
 }
 
+// Wavefronts per stream in the entropy decoder: a batch of more than 8 streams per CU fills the chip with one
+// wave per stream (16 streams per CU fit); smaller ones leave SIMDs idle, and the decoder spends them on the
+// read-ahead (2 waves per stream up to 8 streams per CU, 4 below that).  SQZ_DECODE_WAVES=1|2|4 overrides.
+int decode_waves_for(uint32_t n_blocks) {
+    static const int forced = [] { const char* e = getenv("SQZ_DECODE_WAVES"); return e != NULL ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) { return forced; }
+    int cus = ctx().cus;
+    if (cus <= 0) { cus = 256; }
+    if ((uint64_t)n_blocks <= (uint64_t)cus * 4) { return 4; }
+    if ((uint64_t)n_blocks <= (uint64_t)cus * 8) { return 2; }
+    return 1;
+}
+
 uint32_t match_groups_for(uint64_t avg_block_bytes) {
     static const int div = [] { const char* e = getenv("SQZ_MATCH_DIV"); const int v = e != NULL ? atoi(e) : 1024; return v >= 256 ? v : 1024; }();
     uint64_t g = (avg_block_bytes + div - 1) / div;
@@ -411,7 +424,7 @@ int decode_host(Lane& c, hipStream_t st, const uint8_t* in, const uint64_t* in_o
         sqzk::launch_entropy_decode((const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p,
                                     (const uint64_t*)c.out_off.p, (uint32_t*)c.tokens.p,
                                     (uint32_t*)c.tok_count.p, (int32_t*)c.err.p,
-                                    (uint64_t*)c.end_bit.p, n, start_bit, st);
+                                    (uint64_t*)c.end_bit.p, n, start_bit, decode_waves_for(n), st);
     }
     {
         SpanGuard g(st, SQZ_HIP_K_LZ_EXPAND);
@@ -829,7 +842,7 @@ int sqz_hip_decode_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n
     uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + align_up((uint64_t)n * 4, 256));
     { SpanGuard g((hipStream_t)stream, SQZ_HIP_K_ENTROPY_DECODE);
       sqzk::launch_entropy_decode((const uint8_t*)d_in, d_in_off, d_out_off, tokens, counts, d_err,
-                                  nullptr, n, 0, (hipStream_t)stream); }
+                                  nullptr, n, 0, decode_waves_for(n), (hipStream_t)stream); }
     { SpanGuard g((hipStream_t)stream, SQZ_HIP_K_LZ_EXPAND);
       sqzk::launch_lz_expand(tokens, counts, (uint8_t*)d_out, d_out_off, n, (hipStream_t)stream); }
     return hip_errno(hipGetLastError());

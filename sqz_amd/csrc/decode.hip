@@ -480,6 +480,431 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same decoder with W wavefronts per stream (W = 2, 4), for batches that leave most of the chip idle
+// (at 512 blocks per GPU -- BASELINE.json configs[3] on 8 GPUs -- half of the 1024 SIMDs have no wave at
+// all and one stream is a 60 ms dependent chain).  The read-ahead is what the extra waves are for: with the
+// trees held still, wave w decodes the candidate tokens at bit offsets base + 64 w + lane, all W waves at
+// once; the real token starts are then picked wave after wave (a wave's walk starts where the previous
+// one's left its 64 offsets) -- 64 W offsets per round instead of 64.  Wave 0 alone owns the trees and runs
+// the update side exactly as the one-wave kernel does (bump_batch, the exact path, the stores); the waves
+// meet at workgroup barriers and share their wave-uniform state through a few LDS words, so every wave takes
+// every barrier: there is no spinning and no wave waits for a flag another wave might never set.
+// Tokens a round decodes beyond the 64 a step applies stay in the slots and open the next step's batch.
+// Wave-uniform state the waves hand to each other: written by ONE wave before a barrier, read by all behind
+// it.  Two copies used alternately (steps by their parity, rounds by theirs): a wave that is slow to read
+// what the last barrier published never meets the next writer, who is already filling the other copy --
+// and by the time a copy is written again every wave has passed at least one more barrier.
+struct MwStep {
+    uint32_t run;                       // 0: the stream is finished (or failed): every wave leaves
+    uint32_t m;                         // tokens in the slots
+    uint32_t want;                      // read ahead until this many
+    uint32_t stop;                      // no read-ahead in this step (frozen / very deep trees)
+    uint32_t bit_lo, bit_hi;            // stream bit at which the read-ahead goes on
+};
+struct MwRound {
+    uint32_t entry;                     // offset inside the round's 64 W bits where the walk stands
+    uint32_t m;                         // tokens in the slots
+    uint32_t stop;                      // the walk ran into a token it cannot take (it stands AT that token)
+    uint32_t pad;
+};
+
+template <int W>
+struct DecodeMwLds {
+    TreeLds    tree;
+    DecodeLuts luts;
+    uint32_t   stage[kStageDw];
+    uint32_t   slot[kWave + kWave * W]; // word | (bits used - 1) << 25, in stream order
+    MwStep     step[2];
+    MwRound    round[2];
+};
+
+template <int W>
+__global__ __launch_bounds__(kWave * W, 4)      // 128 VGPRs: 16 waves per CU = 16 / W streams
+void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
+                              const uint64_t* __restrict__ in_off,
+                              const uint64_t* __restrict__ out_off,
+                              uint32_t* __restrict__ tokens,
+                              uint32_t* __restrict__ tok_count,
+                              int32_t* __restrict__ err_out,
+                              uint64_t* __restrict__ end_bit,
+                              uint32_t n_blocks,
+                              uint64_t start_bit) {
+    __shared__ DecodeMwLds<W> lds;
+    const int lane = (int)(threadIdx.x & (kWave - 1));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) { return; }                 // (the whole workgroup)
+
+    LitTree lit; PosTree pos;
+    lit.lds = &lds.tree; lit.code = nullptr; lit.lut = lds.luts.lit;
+    pos.lds = &lds.tree; pos.code = nullptr; pos.lut = lds.luts.pos;
+    lit.init_all(lane);                            // (registers in every wave; the LDS words by wave 0's lanes below)
+    pos.init_all(lane);
+    lds_barrier();
+
+    const uint64_t o0 = uni64(out_off[b]), o1 = uni64(out_off[b + 1]);
+    const uint64_t bytes = o1 - o0;
+    uint32_t* tok = tokens + o0;
+    const uint64_t i0 = uni64(in_off[b]), i1 = uni64(in_off[b + 1]);
+    const uint8_t* const src = in + i0;
+    const uint64_t src_bytes = i1 - i0;
+    const uint64_t readable = (src_bytes / 8) * 64;
+    BitSource r;
+    r.open(src, src_bytes, start_bit, lane);       // (wave 0's is the one that is used)
+    int err = 0;
+    if (wave == 0) {
+        if (!lit.insert_wave(kLitNyt, lane)) { err = kEINVAL; }          // squeeze.h:505-506
+        if (!pos.insert_wave(kPosBase + kPosNyt, lane)) { err = kEINVAL; }
+    }
+    const uint32_t* const lnk = lds.tree.lnk;
+    uint32_t* const slot = lds.slot;
+    uint64_t i = 0;
+    uint32_t ntok = 0;
+
+    auto decode_one = [&]() {                      // squeeze.h:509-549 for exactly one token (wave 0)
+        int s = read_symbol(r, lit, lane, err);
+        if (err != 0) { return; }
+        if (s == kLitNyt) {
+            s = (int)r.get_lsb(9);
+            if (r.overrun()) { err = kE2BIG; return; }
+            if (s == 256 || s >= kLitNyt) { err = kEINVAL; return; }
+            const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit.up_of(s));
+            if (up != kNil) { err = kEINVAL; return; }
+            if (!lit.insert_wave(s, lane)) { err = kE2BIG; return; }
+        }
+        uint32_t word;
+        if (s <= 0xFF) {
+            word = (uint32_t)s;
+            i++;
+        } else {
+            int base, xb;
+            len_base_of(s - kSymLen0, base, xb);
+            int len = base;
+            if (xb != 0) {
+                len += (int)r.get_lsb(xb);
+                if (r.overrun()) { err = kE2BIG; return; }
+            }
+            if (len < kLenMin || len > kLenMax) { err = kEINVAL; return; }
+            int pk = read_symbol(r, pos, lane, err);
+            if (err != 0) { return; }
+            pk -= kPosBase;
+            if (pk == kPosNyt) {
+                pk = (int)r.get_lsb(5);
+                if (r.overrun()) { err = kE2BIG; return; }
+                if (pk >= kPosNyt) { err = kEINVAL; return; }
+                const uint32_t up = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos.up_of(kPosBase + pk));
+                if (up != kNil) { err = kEINVAL; return; }
+                if (!pos.insert_wave(kPosBase + pk, lane)) { err = kE2BIG; return; }
+            }
+            pos_base_of(pk, base, xb);
+            int dist = base;
+            if (xb != 0) {
+                dist += (int)r.get_lsb(xb);
+                if (r.overrun()) { err = kE2BIG; return; }
+            }
+            if (dist > 0x7FFF || (uint64_t)dist > i || (uint64_t)len > bytes - i) { err = kEINVAL; return; }
+            word = kTokMatch | ((uint32_t)len << 16) | (uint32_t)dist;
+            i += (uint64_t)len;
+        }
+        if (lit.fault | pos.fault) { err = kE2BIG; return; }
+        if (lane == 0) { tok[ntok] = word; }
+        ntok++;
+    };
+
+    uint32_t sdw = 0xFFFFFFFFu;                      // stream dword held by stage[0] (every wave keeps the same value)
+    int want = 8, avg4 = 16;
+    const uint64_t quarter = (bytes >> 2) + 1;
+    int prio_now = -1;
+    int kept = 0;                                    // tokens in slot[0, kept) that the last step left valid (wave 0)
+    uint32_t kept_bits = 0;
+    uint32_t step_no = 0, round_no = 0;              // (every wave counts them alike)
+#ifdef SQZ_STATS
+    uint64_t mw_t[6] = {0, 0, 0, 0, 0, 0}, mw_last = __builtin_readcyclecounter();
+#define MW_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); mw_t[k] += n_ - mw_last; mw_last = n_; }
+#else
+#define MW_SEC(k)
+#endif
+    for (;; step_no++) {
+        MwStep& sc = lds.step[step_no & 1u];
+        // ---- wave 0: where the stream stands; the lookup tables -----------------------------------------
+        if (wave == 0) {
+            const bool run = i < bytes && err == 0;
+            bool frozen = true;
+            if (run) {
+                const int q = (int)(i / quarter);
+                if (q != prio_now) {
+                    prio_now = q;
+                    if (q == 0) { __builtin_amdgcn_s_setprio(3); }
+                    else if (q == 1) { __builtin_amdgcn_s_setprio(2); }
+                    else if (q == 2) { __builtin_amdgcn_s_setprio(1); }
+                    else { __builtin_amdgcn_s_setprio(0); }
+                }
+                if (ntok > kBatchTokens && (lit.aux | pos.aux) != 0) { lit.give_up_aux(lane); pos.give_up_aux(lane); }
+                frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
+                         (lit.aux & pos.aux) == 0;
+                if (lit.lut_ok == 0) { lit.build_lut(lane); }
+                if (pos.lut_ok == 0) { pos.build_lut(lane); }
+            }
+            if (frozen) { kept = 0; kept_bits = 0; }
+            if (lane == 0) {
+                const uint64_t at = r.pos + kept_bits;
+                sc.run = run ? 1u : 0u;
+                sc.m = (uint32_t)kept;
+                sc.want = (uint32_t)want;
+                sc.stop = frozen ? 1u : 0u;
+                sc.bit_lo = (uint32_t)at; sc.bit_hi = (uint32_t)(at >> 32);
+            }
+        }
+        MW_SEC(0)
+        lds_barrier();
+        MW_SEC(1)
+        if (__builtin_amdgcn_readfirstlane((int)sc.run) == 0) { break; }
+        const uint64_t bit0 = r.pos;                                     // (wave 0's: where this step's first token starts)
+        uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)sc.bit_hi) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.bit_lo);
+        int m = __builtin_amdgcn_readfirstlane((int)sc.m);
+        const int want_now = __builtin_amdgcn_readfirstlane((int)sc.want);
+        bool stop = __builtin_amdgcn_readfirstlane((int)sc.stop) != 0;
+        // ---- read ahead, all waves: 64 W bit offsets per round -----------------------------------------
+        while (m < want_now && !stop) {
+            const uint32_t k0 = (uint32_t)(base >> 5);
+            if (k0 < sdw || ((uint32_t)((base + (uint64_t)(kWave * W - 1) + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
+                sdw = k0;                                                // (the last round's readers are past their barriers)
+                for (int h = wave * kWave + lane; h < kStageDw; h += kWave * W) {
+                    const uint64_t k = (uint64_t)sdw + (uint32_t)h;
+                    uint32_t v = 0;
+                    if (k * 32 + 32 <= readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
+                    lds.stage[h] = v;
+                }
+                lds_barrier();
+            }
+            // this lane's 64 stream bits from its offset
+            const uint64_t o = base + (uint32_t)(wave * kWave + lane);
+            const uint32_t k = (uint32_t)(o >> 5) - sdw;
+            const int sh = (int)(o & 31u);
+            const uint32_t d0 = lds.stage[k], d1 = lds.stage[k + 1], d2 = lds.stage[k + 2];
+            uint64_t w = ((((uint64_t)d0 << 32) | d1) << sh) | (sh ? ((uint64_t)d2 >> (32 - sh)) : 0ull);
+            // literal / length symbol
+            uint32_t e = lds.luts.lit[(uint32_t)(w >> 56)];
+            uint32_t node = e & 0x3FFu;
+            uint32_t used = e >> 10;
+            w <<= used;
+            for (int it = 0; it < 56; it++) {                      // deeper than the table
+                const bool more = node >= (uint32_t)kLitLeaves && node != kNil;
+                if (__ballot(more) == 0) { break; }
+                if (more) {
+                    const uint32_t kw = lnk[node];
+                    node = (w >> 63) ? l_hi(kw) : l_lo(kw);
+                    w <<= 1;
+                    used++;
+                }
+            }
+            bool bad = node >= (uint32_t)kLitLeaves;              // nil / still inside
+            bool esc = node == (uint32_t)kLitNyt;
+            const bool is_len = !bad && !esc && node > 0xFFu;
+            int bs, xb;
+            len_base_of(is_len ? (int)node - kSymLen0 : 0, bs, xb);
+            const uint32_t len = (uint32_t)bs + (__brev((uint32_t)(w >> 32)) & ((1u << xb) - 1u));
+            w <<= xb;
+            uint32_t more_bits = (uint32_t)xb;
+            const uint32_t e2 = lds.luts.pos[(uint32_t)(w >> (64 - PosTree::kLutBits))];
+            uint32_t n2 = e2 & 0x3FFu;
+            w <<= (e2 >> 10);
+            more_bits += e2 >> 10;
+            for (int it = 0; it < 56; it++) {
+                const bool more = is_len && n2 >= (uint32_t)PosTree::kRoot && n2 != kNil;
+                if (__ballot(more) == 0) { break; }
+                const uint32_t kw = lnk[more ? (int)n2 : (int)PosTree::kRoot];
+                const uint32_t down = (w >> 63) ? l_hi(kw) : l_lo(kw);
+                n2 = more ? down : n2;
+                w <<= more ? 1 : 0;
+                more_bits += more ? 1u : 0u;
+            }
+            const bool pos_bad = n2 >= (uint32_t)PosTree::kRoot;
+            const bool pos_esc = n2 == (uint32_t)(kPosBase + kPosNyt);
+            pos_base_of(pos_bad ? 0 : (int)n2 - kPosBase, bs, xb);
+            const uint32_t dist = (uint32_t)bs + (__brev((uint32_t)(w >> 32)) & ((1u << xb) - 1u));
+            more_bits += (uint32_t)xb;
+            uint32_t word = node;
+            if (is_len) {
+                bad = pos_bad | (len > (uint32_t)kLenMax) | (dist > 0x7FFFu);
+                esc = pos_esc;
+                used += more_bits;
+                word = kTokMatch | (len << 16) | dist;
+            }
+            const bool ok = !bad && !esc && used <= 64u && o + used <= readable;
+            const int hop = ok ? (int)used : 1024;               // a token that cannot be taken jumps far out of the round
+            MW_SEC(2)
+            // ---- the real token starts, wave after wave: wave v follows the lengths through its own 64
+            //      offsets from where wave v-1 left them ---------------------------------------------------
+            MwRound& rc = lds.round[round_no & 1u];
+            round_no++;
+#pragma unroll
+            for (int v = 0; v < W; v++) {
+                if (wave == v) {
+                    // where the walk stands, as an offset inside the round's 64 W bits; this wave's share is
+                    // [64 v, 64 v + 64) (a token is at most 64 bits long, so the walk never jumps over a wave)
+                    uint32_t at = v == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.entry);
+                    int mm = v == 0 ? m : __builtin_amdgcn_readfirstlane((int)rc.m);
+                    uint32_t st = v == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.stop);
+                    uint64_t starts = 0;
+                    if (st == 0 && at < (uint32_t)(kWave * (v + 1))) {
+                        uint32_t s = at - (uint32_t)(kWave * v), last = s;
+                        do {
+                            set_bit64(starts, s);
+                            last = s;
+                            s += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s);
+                        } while (s < (uint32_t)kWave);
+                        if (s >= 1024u) {                          // the last start is the refused one: the walk ends AT it
+                            st = 1;
+                            starts &= ~(1ull << last);
+                            s = last;
+                        }
+                        at = s + (uint32_t)(kWave * v);
+                    }
+                    if ((starts >> lane) & 1ull) {
+                        const int to = mm + (int)lanes_under(starts);
+                        slot[to] = word | ((used - 1u) << 25);
+                    }
+                    mm += __builtin_popcountll(starts);
+                    if (lane == 0) { rc.entry = at; rc.m = (uint32_t)mm; rc.stop = st; }
+                }
+                lds_barrier();
+            }
+            m = __builtin_amdgcn_readfirstlane((int)rc.m);
+            stop = __builtin_amdgcn_readfirstlane((int)rc.stop) != 0;
+            base += (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.entry);     // (stopped: AT the token that cannot be taken)
+            MW_SEC(3)
+        }
+        if (wave != 0) { continue; }                              // (back to the barrier at the top)
+        // =================================================================================================
+        // wave 0: the update side, as in entropy_decode_kernel
+        const int m_total = m;
+        m = m < kWave ? m : kWave;
+        lds_fence();
+        uint32_t word_v = 0, used_v = 0, slot_v = 0;
+        if (lane < m) { slot_v = slot[lane]; word_v = slot_v & 0x81FFFFFFu; used_v = ((slot_v >> 25) & 63u) + 1u; }
+        const bool is_match = (word_v & kTokMatch) != 0;
+        const uint32_t tlen_v = lane < m ? (is_match ? ((word_v >> 16) & 0x1FFu) : 1u) : 0u;
+        uint32_t scan = (used_v << 16) | tlen_v;
+        scan = wave_scan(scan);
+        const uint64_t out_before = i + (uint64_t)((scan & 0xFFFFu) - tlen_v);
+        const bool invalid = lane < m &&
+            (out_before >= bytes ||
+             (is_match && ((uint64_t)(word_v & 0x7FFFu) > out_before || (uint64_t)tlen_v > bytes - out_before)));
+        const uint64_t inv = __ballot(invalid);
+        if (inv != 0) { const int f = __builtin_ctzll(inv); if (f < m) { m = f; stop = true; } }
+        int a_v = -1, b_v = -1;
+        if (lane < m) {
+            if (is_match) {
+                a_v = kSymLen0 + len_code((int)tlen_v).code;
+                b_v = kPosBase + pos_code((int)(word_v & 0x7FFFu)).code;
+            } else {
+                a_v = (int)word_v;
+            }
+        }
+        uint32_t ca, cb;
+        int wa, wb;
+        int done = 0;
+        if (m > 0) { done = bump_batch<false>(&lds.tree, nullptr, lit, pos, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        uint64_t resume = bit0;
+        if (done > 0) {
+            if (lane < done) { tok[ntok + (uint32_t)lane] = word_v; }
+            const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)scan, done - 1);
+            ntok += (uint32_t)done;
+            i += (uint64_t)(af & 0xFFFFu);
+            resume = bit0 + (uint64_t)(af >> 16);
+        }
+        kept = 0; kept_bits = 0;
+        int keep_from = done;                                   // first slot that may open the next step's batch
+        if (i < bytes && (stop || done < m)) {
+            const bool may_keep = done + 1 < m;
+            if (may_keep && lane == 0) {
+                lds.tree.pend[LitTree::kChgSlot] = 0x7FFFFFFFu; lds.tree.pend[LitTree::kChgSlot + 1] = 0u;
+                lds.tree.pend[PosTree::kChgSlot] = 0x7FFFFFFFu; lds.tree.pend[PosTree::kChgSlot + 1] = 0u;
+            }
+            lds_fence();
+            if (done < m) {
+                const int sa = __builtin_amdgcn_readlane(a_v, done), sb = __builtin_amdgcn_readlane(b_v, done);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)word_v, done);
+                const uint32_t u1 = (uint32_t)__builtin_amdgcn_readlane((int)used_v, done);
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)tlen_v, done);
+                { const Chain c = lit.chain_up(sa, lane); (void)lit.bump_wave(sa, c, lane); }
+                if (sb >= 0) { const Chain c = pos.chain_up(sb, lane); (void)pos.bump_wave(sb, c, lane); }
+                if (lit.fault | pos.fault) { err = kE2BIG; }
+                else {
+                    if (lane == 0) { tok[ntok] = w1; }
+                    ntok++;
+                    i += (uint64_t)l1;
+                    r.seek(resume + (uint64_t)u1);
+                }
+            } else {
+                r.seek(resume);
+                decode_one();
+            }
+            lds_fence();
+            const bool still = (lit.complete | pos.complete) == 0 && lit.depth < kFreezeDepth && pos.depth < kFreezeDepth &&
+                               (lit.aux & pos.aux) != 0;
+            if (may_keep && still && err == 0 && i < bytes) {
+                const uint32_t la = lds.tree.pend[LitTree::kChgSlot], ha = lds.tree.pend[LitTree::kChgSlot + 1];
+                const uint32_t lb = lds.tree.pend[PosTree::kChgSlot], hb = lds.tree.pend[PosTree::kChgSlot + 1];
+                const bool cand = lane > done && lane < m;
+                bool moved = false;
+                if (cand) {
+                    const uint32_t qa = r_pos(lds.tree.rng[a_v]);
+                    moved = qa >= la && qa < ha;
+                    if (is_match) { const uint32_t qb = r_pos(lds.tree.rng[b_v]); moved |= qb >= lb && qb < hb; }
+                }
+                const uint64_t behind = ~0ull << (done + 1);
+                const uint64_t ends = (__ballot(!cand || moved) & behind);
+                const int first_out = ends != 0 ? __builtin_ctzll(ends) : kWave;
+                kept = first_out - (done + 1);
+                keep_from = done + 1;
+                if (kept > 0) {
+                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)scan, done) >> 16;
+                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)scan, done + kept) >> 16;
+                    kept_bits = s1 - s0;
+                }
+            }
+        } else {
+            r.seek(resume);
+            // the whole batch went through and nothing stopped the read-ahead: what it decoded beyond the 64
+            // tokens of a step is as valid as they were
+            if (done == m && !stop && m_total > m && i < bytes) {
+                kept = m_total - m < kWave ? m_total - m : kWave;       // (one lane moves one token)
+                keep_from = m;
+                const uint32_t sv = lane < kept ? slot[m + lane] : 0u;
+                kept_bits = wave_sum(lane < kept ? ((sv >> 25) & 63u) + 1u : 0u);
+            }
+        }
+        if (kept > 0 && keep_from > 0) {                           // move them to the front of the slots
+            const uint32_t sv = lane < kept ? slot[keep_from + lane] : 0u;
+            lds_fence();
+            if (lane < kept) { slot[lane] = sv; }
+            lds_fence();
+        }
+        {
+            avg4 += done - (avg4 >> 2);
+            want = ((avg4 * 3) >> 3) + 6;
+            want = want < kWave ? want : kWave;
+        }
+        MW_SEC(4)
+    }
+#ifdef SQZ_STATS
+    if (lane == 0 && b == 1) {
+        printf("mw W=%d wave %d: steps %u rounds %u: top %llu top-barrier %llu decode %llu chain %llu update %llu\n", W, wave, step_no, round_no,
+               (unsigned long long)mw_t[0], (unsigned long long)mw_t[1], (unsigned long long)mw_t[2], (unsigned long long)mw_t[3], (unsigned long long)mw_t[4]);
+    }
+#endif
+    if (wave == 0 && lane == 0) {
+        tok_count[b] = ntok;
+        err_out[b] = err;
+        if (end_bit != nullptr) { end_bit[b] = r.pos; }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // LZ77 expansion (squeeze.h:521-539) with the window where it already is: the output buffer,
 // served by the L2.  A window staged in LDS needs 40 KB per stream -- one wave per SIMD, four
@@ -568,10 +993,19 @@ void lz_expand_kernel(const uint32_t* __restrict__ tokens,
 
 void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
                            uint32_t* tokens, uint32_t* tok_count, int32_t* err, uint64_t* end_bit,
-                           uint32_t n_blocks, uint64_t start_bit, hipStream_t stream) {
+                           uint32_t n_blocks, uint64_t start_bit, int waves, hipStream_t stream) {
     if (n_blocks == 0) { return; }
-    hipLaunchKernelGGL(entropy_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
-                       in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    // waves per stream: 1 when the batch fills the chip by itself (16 streams per CU), 2 / 4 when it does not
+    if (waves >= 4) {
+        hipLaunchKernelGGL(entropy_decode_mw_kernel<4>, dim3(n_blocks), dim3(kWave * 4), 0, stream,
+                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    } else if (waves >= 2) {
+        hipLaunchKernelGGL(entropy_decode_mw_kernel<2>, dim3(n_blocks), dim3(kWave * 2), 0, stream,
+                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    } else {
+        hipLaunchKernelGGL(entropy_decode_kernel, dim3(n_blocks), dim3(kWave), 0, stream,
+                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    }
 }
 
 void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,

@@ -383,7 +383,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         printf("emit block 1: cycles %llu steps %u exact %u: prep %llu bump %llu pack %llu exact %llu\n",
                (unsigned long long)(es_last - es_begin), es_steps, es_exact, (unsigned long long)es[0],
                (unsigned long long)es[1], (unsigned long long)es[2], (unsigned long long)es[3]);
-        for (int k = 0; k < 20; k++) { if (g_secn[k]) { printf("sec %d: %llu cycles / %u = %llu\n", k, g_sec[k], g_secn[k], g_sec[k] / g_secn[k]); } }
+        for (int k = 0; k < 32; k++) { if (g_secn[k]) { printf("sec %d: %llu cycles / %u = %llu\n", k, g_sec[k], g_secn[k], g_sec[k] / g_secn[k]); } }
         printf("emit slow: lit insert %u/%llu changed %u/%llu; pos insert %u/%llu changed %u/%llu\n",
                lit.st_cnt[0], (unsigned long long)lit.st_cyc[0], lit.st_cnt[1], (unsigned long long)lit.st_cyc[1],
                pos.st_cnt[0], (unsigned long long)pos.st_cyc[0], pos.st_cnt[1], (unsigned long long)pos.st_cyc[1]);

@@ -187,6 +187,18 @@ __device__ __forceinline__ void set_bit64(uint64_t& mask, uint32_t bit) {
 #endif
 }
 
+// Workgroup barrier for waves that talk to each other through LDS ONLY.  __syncthreads() also waits for the
+// wave's outstanding global stores (s_waitcnt vmcnt(0): a workgroup-scope release covers global memory too) --
+// the token stores of the decoder's update wave, one to two microseconds each time; here only the LDS
+// traffic has to be in (s_waitcnt lgkmcnt(0)) before the wave stands at the barrier.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef SQZ_WAVE_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

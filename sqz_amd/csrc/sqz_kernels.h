@@ -49,7 +49,7 @@ void launch_tree_debug(const int32_t* symbols, uint32_t count, int which, int ba
 // tokens: one uint32 slot per OUTPUT byte, addressed by out_off; tok_count[n].
 void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint64_t* out_off,
                            uint32_t* tokens, uint32_t* tok_count, int32_t* err, uint64_t* end_bit,
-                           uint32_t n_blocks, uint64_t start_bit, hipStream_t stream);
+                           uint32_t n_blocks, uint64_t start_bit, int waves, hipStream_t stream);
 void launch_lz_expand(const uint32_t* tokens, const uint32_t* tok_count, uint8_t* out,
                       const uint64_t* out_off, uint32_t n_blocks, hipStream_t stream);
 

@@ -114,9 +114,14 @@ __device__ unsigned long long g_sec[32];
 __device__ unsigned int g_secn[32];
 #define SEC_BEGIN uint64_t sec_t_ = __builtin_readcyclecounter();
 #define SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); if (blockIdx.x == 1 && threadIdx.x == 0) { g_sec[k] += n_ - sec_t_; g_secn[k]++; } sec_t_ = n_; }
+// nested sections of the exact path (each function keeps its own start stamp)
+#define XSEC_BEGIN uint64_t xsec_t_ = __builtin_readcyclecounter();
+#define XSEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); if (blockIdx.x == 1 && threadIdx.x == 0) { g_sec[k] += n_ - xsec_t_; g_secn[k]++; } xsec_t_ = n_; }
 #else
 #define SEC_BEGIN
 #define SEC(k)
+#define XSEC_BEGIN
+#define XSEC(k)
 #endif
 
 struct TreeLds {
@@ -377,6 +382,7 @@ struct Tree {
             lds_fence();
             return;
         }
+        XSEC_BEGIN
         // (read by one lane and broadcast: the pass below rewrites positions)
         const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fY));
         const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(fX));
@@ -405,7 +411,9 @@ struct Tree {
             lds->rng[Y] = (lds->rng[Y] & kEndsMask) | (y_partner << 20);  // a hi child against its uncle
         }
         lds_fence();
+        XSEC(13)
         mark_range(p, a, b, want_depth ? wave_max(deepest) : 0u, lane);
+        XSEC(14)
     }
     // the same when the caller knows nothing but p (rare: the order checks of a promotion, the root's pair)
     __device__ __forceinline__ void swap_fix_at(int p, uint32_t dp, int lane) {
@@ -570,6 +578,7 @@ struct Tree {
     // ---------------- a node's root path, one level per lane -------------------------------------
     // lane k receives level k (0 = the start node): one dependent read per level.
     __device__ __forceinline__ Chain chain_up(int s, int lane) const {
+        XSEC_BEGIN
         int a = s, levels = 0;
         int mine = lane == 0 ? s : (int)kNil;
         for (int k = 1; k <= kMaxFastDepth; k++) {
@@ -579,6 +588,7 @@ struct Tree {
             levels = k;
         }
         if (levels == kMaxFastDepth && l_up(lds->lnk[a == (int)kNil ? s : a]) != kNil) { levels = depth_by_walk(s); }   // longer than the wave covers
+        XSEC(8)
         return make_chain(mine, levels, lane);
     }
     __device__ __forceinline__ Chain make_chain(int mine, int levels, int lane) const {
@@ -624,6 +634,7 @@ struct Tree {
     // sibling order per level, the parents' first / last leaves, one pending pair per level (bottom
     // first, appended at pend[sp]) -- and, in registers, which of those pairs would be promoted.
     __device__ __forceinline__ int climb_wave(const Chain& c, int k0, int sp, bool ends_moved, Climbed& out, int lane) {
+        XSEC_BEGIN
         const int levels = c.levels;
         const int span = levels - k0;
         out.hits = 0;
@@ -688,6 +699,7 @@ struct Tree {
             lds->pend[sp + lane - k0] = ((uint32_t)p << 16) | (uint32_t)out.ch;
         }
         lds_fence();
+        XSEC(10)
         if (swaps != 0) {                                             // rare: one pass per exchanged pair
             // my node's own ends: what the lane below computed for its parent (= my node), or the start's
             const uint32_t below_ends = (uint32_t)lane_below((int)ends);
@@ -708,6 +720,7 @@ struct Tree {
                 if (x_hi) { swap_fix((int)pk, (uint32_t)(levels - k - 1), sk, xk, sFk, sLk, xFk, xLk, uk, lane); }
                 else      { swap_fix((int)pk, (uint32_t)(levels - k - 1), xk, sk, xFk, xLk, sFk, sLk, uk, lane); }
             }
+            XSEC(12)
         }
         return sp + span;
     }
@@ -716,6 +729,7 @@ struct Tree {
     // the counts of ch, of the uncle and of p (refreshed) before the move; dg = depth of g.
     __device__ __forceinline__ void promote(int g, uint32_t dg, int p, int ch, int uncle, int left,
                                             uint32_t fch, uint32_t func, uint32_t fpar, int lane) {
+        XSEC_BEGIN
         if (lane == 0) {                                              // :110-119, and p's new sum (:120; g's does not change)
             const uint32_t cw = lds->lnk[ch], gw = lds->lnk[g], pw = lds->lnk[p], uw = lds->lnk[uncle];
             lds->lnk[ch] = (cw & ~0x3FFu) | (uint32_t)g;
@@ -756,6 +770,7 @@ struct Tree {
             uniform_regs();
             lds_fence();
         }
+        XSEC(11)
     }
 
     // huffman_frequency_changed + move_up along the chain `c` of the node whose count changed.  The
@@ -842,6 +857,7 @@ struct Tree {
     // with the incremented counts (swap huffman.h:75, promote :108); no flag -> every count on the
     // chain grows by one, which the lanes do in one step; any flag -> the reference sequence.
     __device__ __forceinline__ uint64_t bump_wave(int s, const Chain& c, int lane) {
+        XSEC_BEGIN
         const int i_mine = c.holds ? c.mine : kRoot;
         const int i_par = c.active ? c.par : kRoot;
         const uint32_t cw = lds->cnt[i_mine];
@@ -864,7 +880,9 @@ struct Tree {
         if (__ballot(flag) == 0) {
             if (c.holds) { lds->cnt[c.mine] = cw + 1; }
             lds_fence();
+            XSEC(9)
         } else {
+            XSEC(9)
             changed_wave(s, c, lane);
         }
         return code_bits;

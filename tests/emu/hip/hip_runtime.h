@@ -1,11 +1,13 @@
 /* tests/emu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
  *
- * A stand-in for <hip/hip_runtime.h> that lets the one-wave-per-stream kernels of
+ * A stand-in for <hip/hip_runtime.h> that lets the stream kernels of
  * sqz_amd/csrc (huffman_emit.hip, decode.hip + sqz_tree.h, sqz_device.h) be compiled by g++
  * and RUN ON THE CPU, lane by lane: the 64 lanes of a wavefront are 64 cooperative fibers
  * (ucontext) on one OS thread; every cross-lane operation (__ballot, readlane, readfirstlane,
- * DPP, ds_bpermute, __shfl_xor, LDS fences, barriers) is a rendezvous where all lanes meet,
- * exchange values and go on.  Between two rendezvous the lanes run one after the other, so the
+ * DPP, ds_bpermute, __shfl_xor, LDS fences) is a rendezvous where all lanes OF THE WAVE meet,
+ * exchange values and go on.  A workgroup may hold several waves (the multi-wave decoder): a wave
+ * runs until it reaches __syncthreads(), where it waits -- the other waves run -- until every wave
+ * that has not finished stands at the barrier (what s_barrier does).  Between two rendezvous the lanes run one after the other, so the
  * emulation is exact for code that talks across lanes only through those operations and
  * through LDS around an lds_fence() -- which is what the kernels do.  A lane that arrives at a
  * different operation than the others (divergent control flow around a cross-lane op) aborts
@@ -44,29 +46,45 @@ typedef void* hipStream_t;
 struct uint4 { uint32_t x, y, z, w; };
 
 namespace emu {
-constexpr int W = 64;
+constexpr int W = 64;             // lanes of a wave
+constexpr int MAXW = 4;           // waves of a workgroup
 struct Lane { ucontext_t ctx; char* stack; bool done; };
-extern Lane g_lane[W];
+struct Wave {
+    Lane lane[W];
+    int cur;                      // lane of this wave running now / to resume
+    int live;                     // lanes that have not returned yet
+    uint64_t slot[2][W];          // values exchanged at a rendezvous (double-buffered by parity)
+    int kind[2][W];               // which operation each lane arrived with
+    uint32_t seq[W];              // rendezvous count per lane
+    uint32_t barriers;            // workgroup barriers this wave has passed or stands at
+    uint32_t lane_barriers[W];    // ... and each of its lanes
+};
+extern Wave g_wave[MAXW];
+extern int g_w;                   // wave running now
+extern int g_waves;               // waves of the running workgroup
 extern ucontext_t g_main;
-extern int g_cur;                 // lane running now
-extern int g_live;                // lanes that have not returned yet
-extern uint64_t g_slot[2][W];     // values exchanged at a rendezvous (double-buffered by parity)
-extern int g_kind[2][W];          // which operation each lane arrived with
-extern uint32_t g_seq[W];         // rendezvous count per lane
 extern unsigned g_block, g_grid;
+#define g_lane g_wave[emu::g_w].lane
+#define g_slot g_wave[emu::g_w].slot
+#define g_cur  g_wave[emu::g_w].cur
 
-// all lanes meet here; returns when every live lane has arrived at ITS rendezvous number seq
+// all lanes of the running wave meet here; returns when every live lane has arrived at ITS rendezvous number
 void rendezvous();
+// the running wave stands at a workgroup barrier: the other waves run until all are there
+void block_barrier();
 // arrive with (kind, value); afterwards slots(par) holds every lane's value
 inline int arrive(int kind, uint64_t v) {
-    const int par = (int)(g_seq[g_cur]++ & 1u);
-    g_slot[par][g_cur] = v;
-    g_kind[par][g_cur] = kind;
+    Wave& wv = g_wave[g_w];
+    const int me = wv.cur;
+    const int par = (int)(wv.seq[me]++ & 1u);
+    wv.slot[par][me] = v;
+    wv.kind[par][me] = kind;
     rendezvous();
+    Wave& w2 = g_wave[g_w];
     for (int l = 0; l < W; l++) {
-        if (!g_lane[l].done && g_kind[par][l] != kind) {
-            fprintf(stderr, "emu: lane %d arrived at operation %d while lane %d is at %d (divergent cross-lane op)\n",
-                    g_cur, kind, l, g_kind[par][l]);
+        if (!w2.lane[l].done && w2.kind[par][l] != kind) {
+            fprintf(stderr, "emu: wave %d lane %d arrived at operation %d while lane %d is at %d (divergent cross-lane op)\n",
+                    g_w, w2.cur, kind, l, w2.kind[par][l]);
             void* bt[32];
             backtrace_symbols_fd(bt, backtrace(bt, 32), 2);
             abort();
@@ -74,13 +92,13 @@ inline int arrive(int kind, uint64_t v) {
     }
     return par;
 }
-void run_block(void (*body)(void*), void* arg, unsigned block, unsigned grid);
+void run_block(void (*body)(void*), void* arg, unsigned block, unsigned grid, unsigned waves);
 }  // namespace emu
 
-struct EmuThreadIdx { struct X { operator unsigned() const { return (unsigned)emu::g_cur; } } x; unsigned y = 0, z = 0; };
+struct EmuThreadIdx { struct X { operator unsigned() const { return (unsigned)(emu::g_w * emu::W + emu::g_wave[emu::g_w].cur); } } x; unsigned y = 0, z = 0; };
 struct EmuBlockIdx { struct X { operator unsigned() const { return emu::g_block; } } x; unsigned y = 0, z = 0; };
 struct EmuGridDim { struct X { operator unsigned() const { return emu::g_grid; } } x; };
-struct EmuBlockDim { struct X { operator unsigned() const { return 64u; } } x; };
+struct EmuBlockDim { struct X { operator unsigned() const { return 64u * (unsigned)emu::g_waves; } } x; };
 static EmuThreadIdx threadIdx;
 static EmuBlockIdx blockIdx;
 static EmuGridDim gridDim;
@@ -140,7 +158,15 @@ inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t base) {
 // one lane's LDS write must be seen by another lane has to be one
 inline void emu_fence() { (void)emu::arrive(7, 0); }
 #define __builtin_amdgcn_fence(order, scope) emu_fence()
-inline void __syncthreads() { emu_fence(); }
+// s_barrier: the wave's lanes meet, then the wave waits for the workgroup's other waves
+inline void __syncthreads() {
+    (void)emu::arrive(8, 0);
+    if (emu::g_waves > 1) {
+        // every lane of the wave passes through here one after the other; the first one to come back from
+        // the rendezvous holds the wave at the barrier, the others find it open already
+        emu::block_barrier();
+    }
+}
 inline void __threadfence_block() { emu_fence(); }
 inline void __builtin_amdgcn_wave_barrier() { emu_fence(); }
 inline void __builtin_amdgcn_s_setprio(int) {}
@@ -175,7 +201,9 @@ template <class F, class... A> struct Thunk {
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 template <class F, class... A> void emu_launch(F f, dim3 grid, dim3 block, A... args) {
-    if (block.x != 64) { fprintf(stderr, "emu: only one-wave workgroups are emulated\n"); abort(); }
+    if (block.x % 64 != 0 || block.x / 64 < 1 || block.x / 64 > (unsigned)emu::MAXW) {
+        fprintf(stderr, "emu: workgroups of 1..%d whole waves are emulated\n", emu::MAXW); abort();
+    }
     emu::Thunk<F, A...> t{f, std::tuple<A...>(args...)};
-    for (unsigned b = 0; b < grid.x; b++) { emu::run_block(&emu::Thunk<F, A...>::run, &t, b, grid.x); }
+    for (unsigned b = 0; b < grid.x; b++) { emu::run_block(&emu::Thunk<F, A...>::run, &t, b, grid.x, block.x / 64); }
 }

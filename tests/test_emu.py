@@ -109,7 +109,7 @@ def emit(E, blocks_tokens, caps):
     return [out[int(out_off[b]):int(out_off[b]) + int(ob[b])].tobytes() for b in range(n)], err
 
 
-def decode(D, streams, sizes):
+def decode(D, streams, sizes, waves=1):
     n = len(streams)
     in_off = np.zeros(n + 1, np.uint64)
     in_off[1:] = np.cumsum([len(s) for s in streams])
@@ -119,7 +119,10 @@ def decode(D, streams, sizes):
     out = np.zeros(int(out_off[-1]) + 8, np.uint8)
     toks = np.zeros(int(out_off[-1]) + 64, np.uint32)
     cnt, err = np.zeros(n, np.uint32), np.zeros(n, np.int32)
-    D.emu_decode(_p(data), _p(in_off), n, _p(out), _p(out_off), _p(toks), _p(cnt), _p(err))
+    if waves == 1:
+        D.emu_decode(_p(data), _p(in_off), n, _p(out), _p(out_off), _p(toks), _p(cnt), _p(err))
+    else:                                     # the multi-wave decoder: `waves` wavefronts per stream
+        D.emu_decode_waves(_p(data), _p(in_off), n, _p(out), _p(out_off), _p(toks), _p(cnt), _p(err), waves)
     return [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(n)], err
 
 
@@ -158,6 +161,36 @@ def test_streams_equal_the_oracle(emu):
     back, derr = decode(D, want, [len(c) for c in cases])
     assert derr.tolist() == [0] * len(cases)
     assert back == [bytes(c) for c in cases]
+    # the same streams through the decoder with 2 and 4 wavefronts per stream (read-ahead over 128 / 256
+    # bit offsets per round, workgroup barriers between the waves: tests/emu runs the waves as they are)
+    for waves in (2, 4):
+        back, derr = decode(D, want, [len(c) for c in cases], waves=waves)
+        assert derr.tolist() == [0] * len(cases), waves
+        assert back == [bytes(c) for c in cases], waves
+
+
+def test_multi_wave_decoder_on_damaged_streams():
+    """errors are the one-wave decoder's (and therefore the hardened oracle's): same errno for truncated and
+    bit-flipped streams, with 2 and 4 waves per stream"""
+    import random
+    D = _build("default", "decode")
+    rng = random.Random(21)
+    data = O.corpus("laozi.txt")[:6000]
+    good = O.encode(data, 12, header=False)
+    streams = [good]
+    for _ in range(10):
+        bad = bytearray(good)
+        bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+        streams.append(bytes(bad))
+    streams += [good[:len(good) // 2 // 8 * 8], good[:8], b""]
+    sizes = [len(data)] * len(streams)
+    base, e1 = decode(D, streams, sizes)
+    for waves in (2, 4):
+        back, e = decode(D, streams, sizes, waves=waves)
+        assert e.tolist() == e1.tolist(), waves
+        for b in range(len(streams)):
+            if e1[b] == 0:
+                assert back[b] == base[b], (waves, b)
 
 
 def test_reference_tree_fixtures_through_the_emulated_kernel():
