@@ -312,7 +312,10 @@ void run_stage1(int finder, const uint8_t* d_in, const uint64_t* d_in_off, uint3
         sqzk::launch_lz77_scan(d_in, d_in_off, n, window, tokens, counts, scan_waves(), slots, st);
     } else {
         { SpanGuard g(st, SQZ_HIP_K_INDEX_SORT);
-          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, tokens /* ping-pong */, work_m, slots, st); }
+          // two arrays serve the three steps: the sort leaves the positions in work_a (work_m is its second
+          // buffer), the match table goes to work_m (the sort is done with it), and the token words may take
+          // work_a's place (tokens == work_a in the encode path: the sorted positions are dead by then)
+          sqzk::launch_index_sort(d_in, d_in_off, n, work_a, work_m /* ping-pong */, nullptr, slots, st); }
         { SpanGuard g(st, SQZ_HIP_K_INDEX_MATCH);
           sqzk::launch_index_match(d_in, d_in_off, n, window, work_a, work_m,
                                    match_groups_for(avg_block), slots, st); }
@@ -347,7 +350,7 @@ int encode_host(Lane& c, hipStream_t st, const uint8_t* in, const uint64_t* in_o
     int e;
     if ((e = c.in.reserve(total_in + 16)) || (e = c.out.reserve(total_out + 16)) ||
         (e = c.in_off.reserve((n + 1) * 8)) || (e = c.out_off.reserve((n + 1) * 8)) ||
-        (e = c.tokens.reserve((total_in + 64) * 4)) || (e = c.tok_count.reserve((size_t)n * 4)) ||
+        (e = c.tok_count.reserve((size_t)n * 4)) ||
         (e = c.work_a.reserve((total_in + 64) * 4)) || (e = c.work_m.reserve((total_in + 64) * 4)) ||
         (e = c.out_bytes.reserve((size_t)n * 8)) || (e = c.err.reserve((size_t)n * 4))) {
         return e;
@@ -358,8 +361,8 @@ int encode_host(Lane& c, hipStream_t st, const uint8_t* in, const uint64_t* in_o
     uint64_t widest = 0;
     for (uint32_t b = 0; b < n; b++) { widest = io[b + 1] - io[b] > widest ? io[b + 1] - io[b] : widest; }
     run_encode(finder_default(), (const uint8_t*)c.in.p, (const uint64_t*)c.in_off.p, n, window,
-               (uint32_t*)c.tokens.p, (uint32_t*)c.tok_count.p, (uint32_t*)c.work_a.p,
-               (uint32_t*)c.work_m.p, widest, (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
+               (uint32_t*)c.work_a.p /* token words take the sorted positions' place */, (uint32_t*)c.tok_count.p,
+               (uint32_t*)c.work_a.p, (uint32_t*)c.work_m.p, widest, (uint8_t*)c.out.p, (const uint64_t*)c.out_off.p,
                (uint64_t*)c.out_bytes.p, (int32_t*)c.err.p, prefix_acc, prefix_fill, total_in + 64, nullptr, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_bytes, c.out_bytes.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
@@ -726,9 +729,9 @@ int sqz_decode_blocks(const uint8_t* in, const uint64_t* in_off, uint32_t n,
 
 // ------------------------------------------------------------------ batch, device
 uint64_t sqz_hip_encode_scratch_bytes(uint32_t n, uint64_t total_in_bytes) {
-    // token counts + three uint32 slots per input byte (tokens / sort ping-pong, sorted
-    // positions, match table)
-    return align_up((uint64_t)n * 4, 256) + 3 * (total_in_bytes + 64) * 4;
+    // token counts + two uint32 slots per input byte: sorted positions, later the token words / the sort's
+    // second buffer, later the match table
+    return align_up((uint64_t)n * 4, 256) + 2 * (total_in_bytes + 64) * 4;
 }
 
 int sqz_hip_lz77_blocks(const void* d_in, const uint64_t* d_in_off, uint32_t n, uint32_t window,
@@ -813,10 +816,10 @@ int sqz_hip_encode_blocks_stats(const void* d_in, const uint64_t* d_in_off, uint
     // without a round trip: the kernels get `slots` and refuse (EINVAL, that block only) any
     // block whose in_off[b+1] lies beyond it.  Offsets are absolute slot indices: in_off[0]
     // need not be 0, but the arrays are addressed by them.
-    const uint64_t slots = (scratch_bytes - head) / 12;    // >= total_in_bytes + 64 by contract
+    const uint64_t slots = (scratch_bytes - head) / 8;     // >= total_in_bytes + 64 by contract
     uint32_t* counts = (uint32_t*)d_scratch;
     uint32_t* tokens = (uint32_t*)((uint8_t*)d_scratch + head);
-    uint32_t* work_a = tokens + slots;
+    uint32_t* work_a = tokens;                             // sorted positions first, the token words afterwards
     uint32_t* work_m = work_a + slots;
     run_encode(finder_default(), (const uint8_t*)d_in, d_in_off, n, window, tokens, counts,
                work_a, work_m, slots / n, (uint8_t*)d_out, d_out_off, d_out_bytes, d_err, 0, 0,

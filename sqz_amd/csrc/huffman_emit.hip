@@ -282,6 +282,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     // streams that are ahead step back (see entropy_decode_kernel): priority 3 -> 0 by quarters
     const uint32_t quarter = (count >> 2) + 1;
     int prio_now = -1;
+    int want = 16, avg4 = 32;                          // (avg4 = 4 x the mean length of the recent steps)
     while (cursor < count && err == 0) {
         {
             const int qq = (int)(cursor / quarter);             // 0..3
@@ -316,6 +317,11 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
         const uint64_t unseen = __ballot(valid && (new_a || new_b || !wellformed));
         const uint64_t vmask = __ballot(valid);
         int m = unseen != 0 ? __builtin_ctzll(unseen) : __builtin_popcountll(vmask);
+        // While the trees are still forming a step ends at a restructure every ten tokens or so: offering all
+        // 64 then means a histogram over tokens that will not be applied and a dozen nodes failing their test,
+        // each of them to be located.  The offer follows the recent step lengths (1.5 x their mean and a
+        // little, the decoder's read-ahead policy); the output does not depend on it.
+        m = m < want ? m : want;
         if (cursor > kBatchTokens && (lit.aux | pos.aux) != 0) {  // counts are about to outgrow their 24 bits
             lit.give_up_aux(lane);
             pos.give_up_aux(lane);
@@ -365,6 +371,11 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 #ifdef SQZ_STATS
         es_steps++;
 #endif
+        {
+            avg4 += (int)(cursor - step_start) - (avg4 >> 2);
+            want = ((avg4 * 3) >> 3) + 6;
+            want = want < kWave ? want : kWave;
+        }
         {   // slide the window by the 1..64 tokens this step consumed
             const uint32_t adv = cursor - step_start;
             const int from = ((lane + (int)adv) & (kWave - 1)) * 4;

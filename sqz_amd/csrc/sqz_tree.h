@@ -389,18 +389,30 @@ struct Tree {
         const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos_of(lX)) + 1u;
         const bool want_depth = p == kRoot || in_insert != 0;
         uint32_t deepest = 0;
+        // one lane per leaf, every row's words read FIRST (a wave alone on its SIMD waits ~100 cycles for
+        // each LDS round trip it takes one after the other: five rows behind five branches were five to
+        // fifteen of them), then the moves
+        uint32_t ws[kLeafRows], cs[kLeafRows], ds[kLeafRows];
 #pragma unroll
         for (int r = 0; r < kLeafRows; r++) {
             const int v = BASE + r * kWave + lane;
-            if (BASE + r * kWave >= kRoot) { break; }
-            const uint32_t w = lds->rng[v < kRoot ? v : kRoot - 1];
+            const int vv = v < kRoot ? v : kRoot - 1;
+            ws[r] = lds->rng[vv];
+            cs[r] = (CODES | want_depth) ? lds->cnt[vv] : 0u;
+            ds[r] = CODES ? code[code_slot(vv)] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (BASE + r * kWave >= kRoot) { continue; }
+            const uint32_t w = ws[r];
             const uint32_t q = r_pos(w);
             const bool in_x = v < kRoot && q >= m && q < b, in_y = v < kRoot && q >= a && q < m;
             if (in_x | in_y) {
                 lds->rng[v] = (w & ~0x1FFu) | (in_x ? q - (m - a) : q + (b - m));
                 if (CODES | want_depth) {
-                    const uint32_t d = c_d(lds->cnt[v]);
-                    if (CODES) { code[code_slot(v)] ^= 1u << (d - 1u - dp); }
+                    const uint32_t d = c_d(cs[r]);
+                    if (CODES) { code[code_slot(v)] = ds[r] ^ (1u << (d - 1u - dp)); }
                     deepest = d > deepest ? d : deepest;
                 }
             }
@@ -449,12 +461,20 @@ struct Tree {
         ga = left ? xa : ua;                                   // g's leaves: the three runs are neighbours
         gb = ga + (uint32_t)(C + U + X);
         uint32_t deepest = 0;
+        uint32_t ws[kLeafRows], cs[kLeafRows], ds[kLeafRows];          // (all rows' words first: see swap_fix)
 #pragma unroll
         for (int r = 0; r < kLeafRows; r++) {
             const int v = BASE + r * kWave + lane;
-            if (BASE + r * kWave >= kRoot) { break; }
             const int vv = v < kRoot ? v : kRoot - 1;
-            const uint32_t w = lds->rng[vv], cw = lds->cnt[vv];
+            ws[r] = lds->rng[vv];
+            cs[r] = lds->cnt[vv];
+            ds[r] = CODES ? code[code_slot(vv)] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (BASE + r * kWave >= kRoot) { continue; }
+            const uint32_t w = ws[r], cw = cs[r];
             const uint32_t q = r_pos(w), d = c_d(cw);
             const bool live = v < kRoot;                         // (a leaf outside the tree is at no position)
             const bool in_c = live && q >= ca && q < cb, in_u = live && q >= ua && q < ub, in_x = live && q >= xa && q < xb;
@@ -466,7 +486,7 @@ struct Tree {
                 if (in_c | in_u) {
                     lds->cnt[v] = in_c ? cw - (1u << kDepthShift) : cw + (1u << kDepthShift);
                     if (CODES) {
-                        const uint32_t old = code[code_slot(v)];
+                        const uint32_t old = ds[r];
                         const uint32_t ls = in_c ? d - dg - 2u : d - dg - 1u;      // bits below the moved node
                         const uint32_t G = dg != 0 ? old >> (d - dg) : 0u;
                         const uint32_t S = old & ((1u << ls) - 1u);
@@ -1016,12 +1036,17 @@ struct Tree {
             // every leaf behind position q moves one to the right; the new leaf takes q + 1
             const int fresh = at;
             const uint32_t leaf_at = l_lo(lds->lnk[fresh]);
+            uint32_t ws[kLeafRows];
 #pragma unroll
             for (int r = 0; r < kLeafRows; r++) {
                 const int v = BASE + r * kWave + lane;
-                if (BASE + r * kWave >= kRoot) { break; }
-                const int vv = v < kRoot ? v : kRoot;
-                const uint32_t w = lds->rng[vv];
+                ws[r] = lds->rng[v < kRoot ? v : kRoot];
+            }
+#pragma unroll
+            for (int r = 0; r < kLeafRows; r++) {
+                const int v = BASE + r * kWave + lane;
+                if (BASE + r * kWave >= kRoot) { continue; }
+                const uint32_t w = ws[r];
                 if (v < kRoot && v != i && r_pos(w) != kNoPos && r_pos(w) > q) { lds->rng[v] = w + 1u; }
             }
             if (lane == 0) {
