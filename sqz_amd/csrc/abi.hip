@@ -281,17 +281,17 @@ int finder_default() {
     return f;
 }
 
-// Wavefronts per stream in the entropy decoder: a batch of more than 8 streams per CU fills the chip with one
-// wave per stream (16 streams per CU fit); smaller ones leave SIMDs idle, and the decoder spends them on the
-// read-ahead (2 waves per stream up to 8 streams per CU, 4 below that).  SQZ_DECODE_WAVES=1|2|4 overrides.
+// Wavefronts per stream in the entropy decoder.  A batch of more than 4 streams per CU runs one wave per
+// stream (16 streams per CU fit: the batch fills the chip by itself); smaller batches leave SIMDs idle and the
+// decoder spends them on the read-ahead: 4 waves per stream (measured, MI355X: 512 blocks 62.4 -> 51.1 ms,
+// 1024 blocks 63.6 -> 54.0 ms; 2 waves per stream gain 2-4 % at best and lose at 2048 blocks, so that step
+// is not taken by default).  SQZ_DECODE_WAVES=1|2|4 overrides.
 int decode_waves_for(uint32_t n_blocks) {
     static const int forced = [] { const char* e = getenv("SQZ_DECODE_WAVES"); return e != NULL ? atoi(e) : 0; }();
     if (forced == 1 || forced == 2 || forced == 4) { return forced; }
     int cus = ctx().cus;
     if (cus <= 0) { cus = 256; }
-    if ((uint64_t)n_blocks <= (uint64_t)cus * 4) { return 4; }
-    if ((uint64_t)n_blocks <= (uint64_t)cus * 8) { return 2; }
-    return 1;
+    return (uint64_t)n_blocks <= (uint64_t)cus * 4 ? 4 : 1;
 }
 
 uint32_t match_groups_for(uint64_t avg_block_bytes) {

@@ -503,12 +503,14 @@ struct MwStep {
     uint32_t stop;                      // no read-ahead in this step (frozen / very deep trees)
     uint32_t bit_lo, bit_hi;            // stream bit at which the read-ahead goes on
 };
-struct MwRound {
-    uint32_t entry;                     // offset inside the round's 64 W bits where the walk stands
-    uint32_t m;                         // tokens in the slots
-    uint32_t stop;                      // the walk ran into a token it cannot take (it stands AT that token)
-    uint32_t pad;
-};
+// Per round and wave: for every one of its 64 offsets, where a walk that STARTS there leaves the wave's share
+// and how many tokens it picks on the way (found for all 64 starts at once by pointer doubling).  With these
+// tables in LDS every wave follows the round's walk through all W shares by itself -- W dependent reads --
+// and then marks its own starts: one barrier per round instead of one per wave.
+//   low byte:  0..63   the walk goes on at that offset of the next wave's share
+//              64 + l  the walk ends AT offset l of this share: the token there cannot be taken
+//   high byte: tokens picked in this share
+struct MwRound { uint16_t exit[4][kWave]; };
 
 template <int W>
 struct DecodeMwLds {
@@ -741,43 +743,52 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
             //      offsets from where wave v-1 left them ---------------------------------------------------
             MwRound& rc = lds.round[round_no & 1u];
             round_no++;
+            {   // pointer doubling over this wave's 64 offsets: to = where the walk stands after cnt tokens
+                uint32_t to = ok ? (uint32_t)lane + used : 128u + (uint32_t)lane;     // < 64: inside; 64..127: out; >= 128: refused here
+                uint32_t cnt = ok ? 1u : 0u;
+#pragma unroll
+                for (int step = 0; step < 6; step++) {
+                    const int from = (int)(to & 63u) << 2;
+                    const uint32_t to2 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)to);
+                    const uint32_t cnt2 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cnt);
+                    const bool inside = to < (uint32_t)kWave;
+                    cnt += inside ? cnt2 : 0u;
+                    to = inside ? to2 : to;
+                }
+                rc.exit[wave][lane] = (uint16_t)((to - (uint32_t)kWave) | (cnt << 8));   // 0..63 next share, 64 + l refused at l
+            }
+            lds_barrier();
+            // the round's walk through all shares (every wave does this alike)
+            uint32_t entry = 0, my_entry = 0;
+            int my_base = m;
+            bool mine = false;
+            uint32_t advance = 0;
 #pragma unroll
             for (int v = 0; v < W; v++) {
-                if (wave == v) {
-                    // where the walk stands, as an offset inside the round's 64 W bits; this wave's share is
-                    // [64 v, 64 v + 64) (a token is at most 64 bits long, so the walk never jumps over a wave)
-                    uint32_t at = v == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.entry);
-                    int mm = v == 0 ? m : __builtin_amdgcn_readfirstlane((int)rc.m);
-                    uint32_t st = v == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.stop);
-                    uint64_t starts = 0;
-                    if (st == 0 && at < (uint32_t)(kWave * (v + 1))) {
-                        uint32_t s = at - (uint32_t)(kWave * v), last = s;
-                        do {
-                            set_bit64(starts, s);
-                            last = s;
-                            s += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s);
-                        } while (s < (uint32_t)kWave);
-                        if (s >= 1024u) {                          // the last start is the refused one: the walk ends AT it
-                            st = 1;
-                            starts &= ~(1ull << last);
-                            s = last;
-                        }
-                        at = s + (uint32_t)(kWave * v);
-                    }
-                    if ((starts >> lane) & 1ull) {
-                        const int to = mm + (int)lanes_under(starts);
-                        slot[to] = word | ((used - 1u) << 25);
-                    }
-                    mm += __builtin_popcountll(starts);
-                    if (lane == 0) { rc.entry = at; rc.m = (uint32_t)mm; rc.stop = st; }
+                if (!stop) {
+                    const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.exit[v][entry]);
+                    if (v == wave) { mine = true; my_entry = entry; my_base = m; }
+                    m += (int)(a >> 8);
+                    const uint32_t fin = a & 0xFFu;
+                    if (fin >= (uint32_t)kWave) { stop = true; advance = (uint32_t)(kWave * v) + (fin - (uint32_t)kWave); }
+                    else { entry = fin; advance = (uint32_t)(kWave * (v + 1)) + fin; }
                 }
-                lds_barrier();
             }
-            m = __builtin_amdgcn_readfirstlane((int)rc.m);
-            stop = __builtin_amdgcn_readfirstlane((int)rc.stop) != 0;
-            base += (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.entry);     // (stopped: AT the token that cannot be taken)
+            if (mine) {                                            // my starts, into the slots (a refused start ends the walk)
+                uint64_t starts = 0;
+                uint32_t s1 = my_entry;
+                while (s1 < (uint32_t)kWave) {
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane(hop, (int)s1);
+                    if (h >= 1024u) { break; }
+                    set_bit64(starts, s1);
+                    s1 += h;
+                }
+                if ((starts >> lane) & 1ull) { slot[my_base + (int)lanes_under(starts)] = word | ((used - 1u) << 25); }
+            }
+            base += advance;                                        // (stopped: AT the token that cannot be taken)
             MW_SEC(3)
         }
+        lds_barrier();                                            // every wave's slots are in
         if (wave != 0) { continue; }                              // (back to the barrier at the top)
         // =================================================================================================
         // wave 0: the update side, as in entropy_decode_kernel
