@@ -283,14 +283,16 @@ int finder_default() {
 
 // Wavefronts per stream in the entropy decoder.  A batch of more than 4 streams per CU runs one wave per
 // stream (16 streams per CU fit: the batch fills the chip by itself); smaller batches leave SIMDs idle and the
-// decoder spends them on the read-ahead: 4 waves per stream (measured, MI355X: 512 blocks 62.4 -> 51.1 ms,
-// 1024 blocks 63.6 -> 54.0 ms; 2 waves per stream gain 2-4 % at best and lose at 2048 blocks, so that step
-// is not taken by default).  SQZ_DECODE_WAVES=1|2|4 overrides.
+// decoder spends them on the read-ahead: 4 waves per stream up to 4 streams per CU, 8 up to 2 (measured,
+// MI355X, entropy_decode_kernel: 512 blocks 62.4 -> 51.4 -> 49.4 ms with 1 / 4 / 8 waves, 1024 blocks
+// 63.6 -> 54.0 ms with 4; 2 waves per stream gain 2-4 % at best and lose at 2048 blocks: not taken).
+// SQZ_DECODE_WAVES=1|2|4|8 overrides.
 int decode_waves_for(uint32_t n_blocks) {
     static const int forced = [] { const char* e = getenv("SQZ_DECODE_WAVES"); return e != NULL ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 4) { return forced; }
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) { return forced; }
     int cus = ctx().cus;
     if (cus <= 0) { cus = 256; }
+    if ((uint64_t)n_blocks <= (uint64_t)cus * 2) { return 8; }
     return (uint64_t)n_blocks <= (uint64_t)cus * 4 ? 4 : 1;
 }
 

@@ -510,7 +510,7 @@ struct MwStep {
 //   low byte:  0..63   the walk goes on at that offset of the next wave's share
 //              64 + l  the walk ends AT offset l of this share: the token there cannot be taken
 //   high byte: tokens picked in this share
-struct MwRound { uint16_t exit[4][kWave]; };
+struct MwRound { uint16_t exit[8][kWave]; };
 
 template <int W>
 struct DecodeMwLds {
@@ -1007,7 +1007,10 @@ void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint
                            uint32_t n_blocks, uint64_t start_bit, int waves, hipStream_t stream) {
     if (n_blocks == 0) { return; }
     // waves per stream: 1 when the batch fills the chip by itself (16 streams per CU), 2 / 4 when it does not
-    if (waves >= 4) {
+    if (waves >= 8) {
+        hipLaunchKernelGGL(entropy_decode_mw_kernel<8>, dim3(n_blocks), dim3(kWave * 8), 0, stream,
+                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    } else if (waves >= 4) {
         hipLaunchKernelGGL(entropy_decode_mw_kernel<4>, dim3(n_blocks), dim3(kWave * 4), 0, stream,
                            in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
     } else if (waves >= 2) {

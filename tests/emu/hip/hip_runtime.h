@@ -47,7 +47,7 @@ struct uint4 { uint32_t x, y, z, w; };
 
 namespace emu {
 constexpr int W = 64;             // lanes of a wave
-constexpr int MAXW = 4;           // waves of a workgroup
+constexpr int MAXW = 8;           // waves of a workgroup
 struct Lane { ucontext_t ctx; char* stack; bool done; };
 struct Wave {
     Lane lane[W];

@@ -163,7 +163,7 @@ def test_streams_equal_the_oracle(emu):
     assert back == [bytes(c) for c in cases]
     # the same streams through the decoder with 2 and 4 wavefronts per stream (read-ahead over 128 / 256
     # bit offsets per round, workgroup barriers between the waves: tests/emu runs the waves as they are)
-    for waves in (2, 4):
+    for waves in (2, 4, 8):
         back, derr = decode(D, want, [len(c) for c in cases], waves=waves)
         assert derr.tolist() == [0] * len(cases), waves
         assert back == [bytes(c) for c in cases], waves
@@ -171,7 +171,7 @@ def test_streams_equal_the_oracle(emu):
 
 def test_multi_wave_decoder_on_damaged_streams():
     """errors are the one-wave decoder's (and therefore the hardened oracle's): same errno for truncated and
-    bit-flipped streams, with 2 and 4 waves per stream"""
+    bit-flipped streams, with 2, 4 and 8 waves per stream"""
     import random
     D = _build("default", "decode")
     rng = random.Random(21)
@@ -185,7 +185,7 @@ def test_multi_wave_decoder_on_damaged_streams():
     streams += [good[:len(good) // 2 // 8 * 8], good[:8], b""]
     sizes = [len(data)] * len(streams)
     base, e1 = decode(D, streams, sizes)
-    for waves in (2, 4):
+    for waves in (2, 4, 8):
         back, e = decode(D, streams, sizes, waves=waves)
         assert e.tolist() == e1.tolist(), waves
         for b in range(len(streams)):

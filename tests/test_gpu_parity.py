@@ -656,3 +656,57 @@ def test_reference_counters(sq, batch):
             i = rows.index(g)
             got = out[int(out_off[i]):int(out_off[i]) + nb].cpu().numpy().tobytes()
             assert got == O.encode(data, wb, header=False)
+
+
+# ---------------------------------------------------------------- decoder: waves per stream
+_WAVES_CHECK = r"""
+import os, sys
+sys.path[:0] = [os.environ["SQZ_ROOT"], os.path.join(os.environ["SQZ_ROOT"], "tests")]
+import numpy as np, torch
+import oracle_lib as O
+import sqz_amd
+from sqz_amd import batch
+# good streams of the oracle: corpus pieces, Zipf blocks, degenerate inputs; then damaged ones
+cases = [O.corpus("laozi.txt")[:9000], O.zipf_block(3, 16384), b"", b"a", b"abcabcabc" * 40, bytes(range(256)) * 6,
+         bytes(5000), O.corpus("confucius.txt")[20000:32000], O.corpus("x64.elf")[4096:20480]]
+streams = [O.encode(c, 12, header=False) for c in cases]
+back, err = batch.decode_blocks_host(streams, [len(c) for c in cases])
+assert err.tolist() == [0] * len(cases), err.tolist()
+assert back == [bytes(c) for c in cases]
+import random
+rng = random.Random(5)
+good = streams[0]
+bad = []
+for _ in range(12):
+    s = bytearray(good)
+    s[rng.randrange(len(s))] ^= 1 << rng.randrange(8)
+    bad.append(bytes(s))
+bad += [good[:len(good) // 2 // 8 * 8], good[:8]]
+got, e = batch.decode_blocks_host(bad, [len(cases[0])] * len(bad))
+want = [O.decode(s, header=False, nbytes=len(cases[0]))[0] for s in bad]
+assert e.tolist() == want, (e.tolist(), want)
+# a device-resident batch of the benchmark's blocks, round trip
+n, bb = 24, 65536
+d_in = batch.zipf_blocks(n, bb)
+off = batch.uniform_offsets(n, bb)
+enc = batch.Encoder(n, n * bb, sqz_amd.bound(bb))
+out, out_off, out_bytes, err = enc.encode(d_in, off, 1 << 15)
+d_back = torch.zeros_like(d_in)
+derr = batch.decode_blocks(out, out_off, n, d_back, off)
+torch.cuda.synchronize()
+assert int(derr.abs().sum()) == 0 and torch.equal(d_back, d_in)
+print("waves ok", os.environ.get("SQZ_DECODE_WAVES"))
+"""
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_decoder_with_1_2_4_8_waves_per_stream(sq, waves):
+    """the decoder picks its wavefronts per stream from the batch size (1 for batches that fill the chip, 4 / 8
+    below that): every setting forced in a fresh process (SQZ_DECODE_WAVES is read once), on good streams, on
+    damaged ones (same errno as the hardened oracle) and on a device-resident round trip"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SQZ_DECODE_WAVES=str(waves), SQZ_ROOT=root)
+    p = subprocess.run([sys.executable, "-c", _WAVES_CHECK], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and f"waves ok {waves}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
