@@ -502,6 +502,8 @@ struct MwStep {
     uint32_t want;                      // read ahead until this many
     uint32_t stop;                      // no read-ahead in this step (frozen / very deep trees)
     uint32_t bit_lo, bit_hi;            // stream bit at which the read-ahead goes on
+    uint32_t solo;                      // this step's read-ahead is wave 0's alone
+    uint32_t sdw;                       // stream dword the staged window starts at
 };
 // Per round and wave: for every one of its 64 offsets, where a walk that STARTS there leaves the wave's share
 // and how many tokens it picks on the way (found for all 64 starts at once by pointer doubling).  With these
@@ -511,6 +513,8 @@ struct MwStep {
 //              64 + l  the walk ends AT offset l of this share: the token there cannot be taken
 //   high byte: tokens picked in this share
 struct MwRound { uint16_t exit[8][kWave]; };
+
+constexpr int kMwSoloWant = 24;         // steps that want no more tokens than this are read ahead by wave 0 alone
 
 template <int W>
 struct DecodeMwLds {
@@ -621,15 +625,23 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
     int prio_now = -1;
     int kept = 0;                                    // tokens in slot[0, kept) that the last step left valid (wave 0)
     uint32_t kept_bits = 0;
-    uint32_t step_no = 0, round_no = 0;              // (every wave counts them alike)
+    uint32_t step_no = 0, round_no = 0;              // shared steps and rounds (every wave counts them alike)
 #ifdef SQZ_STATS
-    uint64_t mw_t[6] = {0, 0, 0, 0, 0, 0}, mw_last = __builtin_readcyclecounter();
+    uint64_t mw_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mw_last = __builtin_readcyclecounter();
+    uint32_t mw_solo_rounds = 0, mw_steps = 0, mw_done = 0;
 #define MW_SEC(k) { const uint64_t n_ = __builtin_readcyclecounter(); mw_t[k] += n_ - mw_last; mw_last = n_; }
 #else
 #define MW_SEC(k)
 #endif
-    for (;; step_no++) {
-        MwStep& sc = lds.step[step_no & 1u];
+    // Wave 0 meets the other waves only in the steps whose read-ahead they take part in (and at the very end):
+    // a SOLO step -- wave 0 reads ahead by itself, see below -- has no barrier in it at all, and while wave 0
+    // makes one solo step after the other the other waves stand at the barrier at the top of their loop.
+    for (;;) {
+        MwStep& sc = lds.step[step_no & 1u];                  // (step_no counts the steps the waves share)
+        bool shared = true;
+        uint64_t base = 0;
+        int m = 0, want_now = 0;
+        bool stop = false, solo = false;
         // ---- wave 0: where the stream stands; the lookup tables -----------------------------------------
         if (wave == 0) {
             const bool run = i < bytes && err == 0;
@@ -650,40 +662,39 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
                 if (pos.lut_ok == 0) { pos.build_lut(lane); }
             }
             if (frozen) { kept = 0; kept_bits = 0; }
-            if (lane == 0) {
-                const uint64_t at = r.pos + kept_bits;
-                sc.run = run ? 1u : 0u;
-                sc.m = (uint32_t)kept;
-                sc.want = (uint32_t)want;
-                sc.stop = frozen ? 1u : 0u;
-                sc.bit_lo = (uint32_t)at; sc.bit_hi = (uint32_t)(at >> 32);
+            const uint64_t at = r.pos + kept_bits;
+            solo = run && (frozen || want <= kMwSoloWant);
+            shared = !solo;
+            if (shared) {   // lane k writes word k of the step's shared words (run, m, want, stop, bit_lo, bit_hi, -, sdw)
+                const uint32_t v = lane == 0 ? (run ? 1u : 0u) : lane == 1 ? (uint32_t)kept : lane == 2 ? (uint32_t)want
+                                 : lane == 3 ? (frozen ? 1u : 0u) : lane == 4 ? (uint32_t)at : lane == 5 ? (uint32_t)(at >> 32)
+                                 : lane == 6 ? 0u : sdw;
+                if (lane < 8) { reinterpret_cast<uint32_t*>(&sc)[lane] = v; }
+            } else {
+                base = at; m = kept; want_now = want; stop = frozen;
             }
         }
         MW_SEC(0)
-        lds_barrier();
-        MW_SEC(1)
-        if (__builtin_amdgcn_readfirstlane((int)sc.run) == 0) { break; }
         const uint64_t bit0 = r.pos;                                     // (wave 0's: where this step's first token starts)
-        uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)sc.bit_hi) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.bit_lo);
-        int m = __builtin_amdgcn_readfirstlane((int)sc.m);
-        const int want_now = __builtin_amdgcn_readfirstlane((int)sc.want);
-        bool stop = __builtin_amdgcn_readfirstlane((int)sc.stop) != 0;
-        // ---- read ahead, all waves: 64 W bit offsets per round -----------------------------------------
-        while (m < want_now && !stop) {
-            const uint32_t k0 = (uint32_t)(base >> 5);
-            if (k0 < sdw || ((uint32_t)((base + (uint64_t)(kWave * W - 1) + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
-                sdw = k0;                                                // (the last round's readers are past their barriers)
-                for (int h = wave * kWave + lane; h < kStageDw; h += kWave * W) {
-                    const uint64_t k = (uint64_t)sdw + (uint32_t)h;
-                    uint32_t v = 0;
-                    if (k * 32 + 32 <= readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
-                    lds.stage[h] = v;
-                }
-                lds_barrier();
-            }
+        if (shared) {
+            lds_barrier();
+            MW_SEC(1)
+            step_no++;
+            // the step's shared words: ONE read (lane k takes word k), then out of the register
+            const uint32_t scw = reinterpret_cast<const uint32_t*>(&sc)[lane & 7];
+            static_assert(sizeof(MwStep) == 32, "eight words");
+            if (__builtin_amdgcn_readlane((int)scw, 0) == 0) { break; }      // run
+            base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)scw, 5) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)scw, 4);
+            m = __builtin_amdgcn_readlane((int)scw, 1);
+            want_now = __builtin_amdgcn_readlane((int)scw, 2);
+            stop = __builtin_amdgcn_readlane((int)scw, 3) != 0;
+            sdw = (uint32_t)__builtin_amdgcn_readlane((int)scw, 7);
+        }
+        // the candidate token at stream bit o (squeeze.h:458-500, read only): its word, the bits it takes, and
+        // whether it can be taken here (no escape, nothing malformed, inside the readable bits)
+        auto candidate = [&](uint64_t o, uint32_t& word_out, uint32_t& used_out, bool& ok) {
             // this lane's 64 stream bits from its offset
-            const uint64_t o = base + (uint32_t)(wave * kWave + lane);
             const uint32_t k = (uint32_t)(o >> 5) - sdw;
             const int sh = (int)(o & 31u);
             const uint32_t d0 = lds.stage[k], d1 = lds.stage[k + 1], d2 = lds.stage[k + 2];
@@ -736,7 +747,68 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
                 used += more_bits;
                 word = kTokMatch | (len << 16) | dist;
             }
-            const bool ok = !bad && !esc && used <= 64u && o + used <= readable;
+            ok = !bad && !esc && used <= 64u && o + used <= readable;
+            word_out = word;
+            used_out = used;
+        };
+        // ---- read ahead -----------------------------------------------------------------------------------
+        if (solo) {
+            // Short steps (the trees are still forming, or the data keeps them moving: a restructure every few
+            // tokens): a round of 64 W offsets would decode far more than the step can use and pay a barrier
+            // for it.  Wave 0 reads ahead by itself, 64 offsets per round, as the one-wave kernel does, and
+            // meets no barrier in such a step.
+            if (wave == 0) {
+                while (m < want_now && !stop) {
+                    const uint32_t k0 = (uint32_t)(base >> 5);
+                    if (k0 < sdw || ((uint32_t)((base + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
+                        sdw = k0;
+                        for (int h = lane; h < kStageDw; h += kWave) {
+                            const uint64_t k = (uint64_t)sdw + (uint32_t)h;
+                            uint32_t v = 0;
+                            if (k * 32 + 32 <= readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
+                            lds.stage[h] = v;
+                        }
+                        lds_fence();
+                    }
+                    uint32_t word, used; bool ok;
+                    candidate(base + (uint32_t)lane, word, used, ok);
+#ifdef SQZ_STATS
+                    mw_solo_rounds++;
+#endif
+                    const int hop = ok ? (int)used : 128;
+                    uint64_t starts = 0;
+                    uint32_t s1 = 0;
+                    do {
+                        set_bit64(starts, s1);
+                        s1 += (uint32_t)__builtin_amdgcn_readlane(hop, (int)s1);
+                    } while (s1 < (uint32_t)kWave);
+                    if (s1 >= 128u) {                              // the last start is the refused one
+                        stop = true;
+                        const int last = 63 - __builtin_clzll(starts);
+                        starts &= ~(1ull << last);
+                        s1 = (uint32_t)last;
+                    }
+                    base += s1;
+                    if ((starts >> lane) & 1ull) { slot[m + (int)lanes_under(starts)] = word | ((used - 1u) << 25); }
+                    m += __builtin_popcountll(starts);
+                }
+            }
+        } else {
+        // all waves: 64 W bit offsets per round
+        while (m < want_now && !stop) {
+            const uint32_t k0 = (uint32_t)(base >> 5);
+            if (k0 < sdw || ((uint32_t)((base + (uint64_t)(kWave * W - 1) + 63) >> 5) + 2 - sdw) >= (uint32_t)kStageDw) {
+                sdw = k0;                                                // (the last round's readers are past their barriers)
+                for (int h = wave * kWave + lane; h < kStageDw; h += kWave * W) {
+                    const uint64_t k = (uint64_t)sdw + (uint32_t)h;
+                    uint32_t v = 0;
+                    if (k * 32 + 32 <= readable) { v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(src)[k]); }
+                    lds.stage[h] = v;
+                }
+                lds_barrier();
+            }
+            uint32_t word, used; bool ok;
+            candidate(base + (uint32_t)(wave * kWave + lane), word, used, ok);
             const int hop = ok ? (int)used : 1024;               // a token that cannot be taken jumps far out of the round
             MW_SEC(2)
             // ---- the real token starts, wave after wave: wave v follows the lengths through its own 64
@@ -788,7 +860,9 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
             base += advance;                                        // (stopped: AT the token that cannot be taken)
             MW_SEC(3)
         }
-        lds_barrier();                                            // every wave's slots are in
+        }
+        MW_SEC(5)
+        if (shared) { lds_barrier(); }                            // every wave's slots are in
         if (wave != 0) { continue; }                              // (back to the barrier at the top)
         // =================================================================================================
         // wave 0: the update side, as in entropy_decode_kernel
@@ -819,7 +893,15 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
         uint32_t ca, cb;
         int wa, wb;
         int done = 0;
+        MW_SEC(6)
+#ifdef SQZ_STATS
+        mw_steps++;
+#endif
         if (m > 0) { done = bump_batch<false>(&lds.tree, nullptr, lit, pos, lane, m, a_v, b_v, ca, wa, cb, wb); }
+        MW_SEC(7)
+#ifdef SQZ_STATS
+        mw_done += (uint32_t)done;
+#endif
         uint64_t resume = bit0;
         if (done > 0) {
             if (lane < done) { tok[ntok + (uint32_t)lane] = word_v; }
@@ -905,8 +987,10 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
     }
 #ifdef SQZ_STATS
     if (lane == 0 && b == 1) {
-        printf("mw W=%d wave %d: steps %u rounds %u: top %llu top-barrier %llu decode %llu chain %llu update %llu\n", W, wave, step_no, round_no,
-               (unsigned long long)mw_t[0], (unsigned long long)mw_t[1], (unsigned long long)mw_t[2], (unsigned long long)mw_t[3], (unsigned long long)mw_t[4]);
+        printf("mw all steps %u solo rounds %u tokens %u done-by-batches %u\n", mw_steps, mw_solo_rounds, ntok, mw_done);
+        printf("mw W=%d wave %d: shared steps %u rounds %u: top %llu top-barrier %llu decode %llu chain %llu solo-readahead %llu post %llu bump %llu rest %llu\n", W, wave, step_no, round_no,
+               (unsigned long long)mw_t[0], (unsigned long long)mw_t[1], (unsigned long long)mw_t[2], (unsigned long long)mw_t[3], (unsigned long long)mw_t[5],
+               (unsigned long long)mw_t[6], (unsigned long long)mw_t[7], (unsigned long long)mw_t[4]);
     }
 #endif
     if (wave == 0 && lane == 0) {
@@ -1012,6 +1096,9 @@ void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint
                            in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
     } else if (waves >= 4) {
         hipLaunchKernelGGL(entropy_decode_mw_kernel<4>, dim3(n_blocks), dim3(kWave * 4), 0, stream,
+                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
+    } else if (waves == 3) {        // (development: the multi-wave kernel's code with one wave)
+        hipLaunchKernelGGL(entropy_decode_mw_kernel<1>, dim3(n_blocks), dim3(kWave), 0, stream,
                            in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
     } else if (waves >= 2) {
         hipLaunchKernelGGL(entropy_decode_mw_kernel<2>, dim3(n_blocks), dim3(kWave * 2), 0, stream,

@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch, sqz_amd
 from sqz_amd import batch
 
-BB, N = 262144, 1024
+BB, N = 262144, int(os.environ.get("CORPUS_BLOCKS", "1024"))
+ONLY = os.environ.get("CORPUS_ONLY")          # comma-separated case names
 def blocks_from(data, n):
     data = np.frombuffer(data, np.uint8)
     reps = (n * BB + len(data) - 1) // len(data)
@@ -24,6 +25,8 @@ cases["uniform random"] = rng.integers(0, 256, N * BB, dtype=np.uint8)
 off = batch.uniform_offsets(N, BB)
 enc = batch.Encoder(N, N * BB, sqz_amd.bound(BB))
 for name, arr in cases.items():
+    if ONLY and name not in ONLY.split(","):
+        continue
     d_in = torch.tensor(arr, device="cuda")
     back = torch.empty_like(d_in)
     derr = torch.zeros(N, dtype=torch.int32, device="cuda")
