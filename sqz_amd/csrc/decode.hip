@@ -212,6 +212,7 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
     // step's batch without being decoded again
     int kept = 0;
     uint32_t kept_bits = 0, kept_slot = 0;
+    uint32_t regain_at = 0;                          // next look at a tree that has given up its positions
     while (i < bytes && err == 0) {
         {
             const int q = (int)(i / quarter);                  // 0..3
@@ -226,6 +227,12 @@ void entropy_decode_kernel(const uint8_t* __restrict__ in,
         if (ntok > kBatchTokens && (lit.aux | pos.aux) != 0) {     // counts are about to outgrow their 24 bits
             lit.give_up_aux(lane);
             pos.give_up_aux(lane);
+        }
+        if ((lit.aux & pos.aux) == 0 && ntok <= kBatchTokens && ntok >= regain_at) {
+            // a tree that was too deep for the position machinery may have settled (sqz_tree.h: regain_aux)
+            regain_at = ntok + 512u;
+            (void)lit.regain_aux(lane);
+            (void)pos.regain_aux(lane);
         }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
                             (lit.aux & pos.aux) == 0;
@@ -626,6 +633,7 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
     int kept = 0;                                    // tokens in slot[0, kept) that the last step left valid (wave 0)
     uint32_t kept_bits = 0;
     uint32_t step_no = 0, round_no = 0;              // shared steps and rounds (every wave counts them alike)
+    uint32_t regain_at = 0;                          // (wave 0) next look at a tree that has given up its positions
 #ifdef SQZ_STATS
     uint64_t mw_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mw_last = __builtin_readcyclecounter();
     uint32_t mw_solo_rounds = 0, mw_steps = 0, mw_done = 0;
@@ -656,6 +664,11 @@ void entropy_decode_mw_kernel(const uint8_t* __restrict__ in,
                     else { __builtin_amdgcn_s_setprio(0); }
                 }
                 if (ntok > kBatchTokens && (lit.aux | pos.aux) != 0) { lit.give_up_aux(lane); pos.give_up_aux(lane); }
+                if ((lit.aux & pos.aux) == 0 && ntok <= kBatchTokens && ntok >= regain_at) {
+                    regain_at = ntok + 512u;
+                    (void)lit.regain_aux(lane);
+                    (void)pos.regain_aux(lane);
+                }
                 frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
                          (lit.aux & pos.aux) == 0;
                 if (lit.lut_ok == 0) { lit.build_lut(lane); }

@@ -283,6 +283,7 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
     const uint32_t quarter = (count >> 2) + 1;
     int prio_now = -1;
     int want = 16, avg4 = 32;                          // (avg4 = 4 x the mean length of the recent steps)
+    uint32_t regain_at = 0;                            // next look at a tree that has given up its positions
     while (cursor < count && err == 0) {
         {
             const int qq = (int)(cursor / quarter);             // 0..3
@@ -326,6 +327,12 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
             lit.give_up_aux(lane);
             pos.give_up_aux(lane);
         }
+        if ((lit.aux & pos.aux) == 0 && cursor <= kBatchTokens && cursor >= regain_at) {
+            // a tree that was too deep for the position machinery may have settled (sqz_tree.h: regain_aux)
+            regain_at = cursor + 512u;
+            (void)lit.regain_aux(lane);
+            (void)pos.regain_aux(lane);
+        }
         const bool frozen = (lit.complete | pos.complete) != 0 || lit.depth >= kFreezeDepth || pos.depth >= kFreezeDepth ||
                             (lit.aux & pos.aux) == 0;
         uint32_t ca = 0, cb = 0;
@@ -368,6 +375,17 @@ void huffman_emit_kernel(const uint32_t* __restrict__ tokens,
 #endif
         }
         ES(3)
+#ifdef SQZ_EMU_DEBUG_BATCH
+        if (lane == 0) {
+            static unsigned dbg_steps = 0, dbg_offered = 0, dbg_applied = 0, dbg_exact = 0, dbg_next = 16384;
+            dbg_steps++; dbg_offered += (unsigned)offered; dbg_applied += (unsigned)m; dbg_exact += (m < offered || offered == 0 || frozen) ? 1u : 0u;
+            if (cursor >= dbg_next || cursor >= count) {
+                fprintf(stderr, "cursor %u: steps %u offered %u applied %u exact %u (want %d) depth %d/%d aux %d/%d\n", cursor, dbg_steps, dbg_offered, dbg_applied, dbg_exact, want,
+                        lit.depth, pos.depth, lit.aux, pos.aux);
+                dbg_steps = dbg_offered = dbg_applied = dbg_exact = 0; dbg_next = cursor + 16384;
+            }
+        }
+#endif
 #ifdef SQZ_STATS
         es_steps++;
 #endif

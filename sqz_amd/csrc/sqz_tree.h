@@ -289,10 +289,118 @@ struct Tree {
         fault = __builtin_amdgcn_readfirstlane(fault);
         aux = __builtin_amdgcn_readfirstlane(aux);
     }
-    // the reference's high-water mark moved: a tree this deep gives up the position machinery
+    // the reference's high-water mark moved; a tree that is (now) this deep gives up the position machinery.
+    // (d is the depth of the deepest leaf the restructure touched -- every change of a depth comes through
+    // here with it -- so the machinery follows the tree as it IS; the mark only gates the freeze, huffman.h:228)
     __device__ __forceinline__ void raise_mark(int d, int lane) {
         if (d > depth) { depth = d; }
-        if (depth >= kAuxDepth) { give_up_aux(lane); }
+        if (d >= kAuxDepth) { give_up_aux(lane); }
+    }
+
+    // Back to the position machinery.  A burst of symbols seen once each builds a chain down the tree's left
+    // edge (huffman_insert always splits the leftmost leaf it reaches, and nothing moves while all counts are
+    // equal): uniform random bytes pass depth 26 within their first fifty symbols in one 256 KB block out of
+    // thirty -- and that block then took the one-at-a-time path for all its 260,000 tokens, ten times the cost
+    // of its neighbours, although its tree had settled at depth 10 after a few hundred symbols.  Everything the
+    // machinery keeps is a function of the links: it is rebuilt here, whole wave, once the tree is shallow
+    // again (with a margin, so that it does not flap): every leaf's depth and code by a walk to the root, its
+    // position as its rank among the codes (depth-first order IS the order of the left-aligned codes), every
+    // internal node's first and last leaf by a walk down, every node's test partner.  About 40 k cycles.
+    // Returns whether the tree keeps positions afterwards.
+    __device__ __forceinline__ bool regain_aux(int lane) {
+        if (aux != 0) { return true; }
+        if (complete != 0) { return false; }
+        constexpr int kInnerRows = (NODES - LEAVES + kWave - 1) / kWave;
+        constexpr uint32_t kRegainDepth = kAuxDepth > 8 ? kAuxDepth - 4 : (kAuxDepth > 2 ? kAuxDepth - 2 : 1);
+        uint32_t key[kLeafRows], dep[kLeafRows], cod[kLeafRows];
+        bool in[kLeafRows];
+        bool deep = false;
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            const int vv = v < kRoot ? v : kRoot - 1;
+            in[r] = v < kRoot && l_up(lds->lnk[vv]) != kNil;
+            uint32_t a = (uint32_t)vv, c = 0, d = 0;
+            for (int it = 0; it <= kAuxDepth; it++) {
+                const uint32_t up = l_up(lds->lnk[a]);
+                const bool more = in[r] && up != kNil;
+                if (__ballot(more) == 0) { break; }
+                const uint32_t pw = lds->lnk[more ? up : (uint32_t)kRoot];
+                if (more) { c |= (l_hi(pw) == a ? 1u : 0u) << d; d++; a = up; }
+            }
+            deep |= in[r] && (d > kRegainDepth || l_up(lds->lnk[a]) != kNil);
+            dep[r] = d; cod[r] = c;
+            key[r] = d != 0 ? c << (32u - d) : 0u;
+        }
+        if (__ballot(deep) != 0) { return false; }
+        // ranks: the keys wait in the leaves' range words (stale while the positions were given up)
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (v < kRoot) { lds->rng[v] = in[r] ? key[r] : 0xFFFFFFFFu; }
+        }
+        lds_fence();
+        uint32_t rank[kLeafRows];
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) { rank[r] = 0; }
+        for (int u = 0; u < LEAVES; u += 4) {
+            const uint32_t k0 = lds->rng[BASE + u], k1 = lds->rng[BASE + u + 1], k2 = lds->rng[BASE + u + 2], k3 = lds->rng[BASE + u + 3];
+#pragma unroll
+            for (int r = 0; r < kLeafRows; r++) {
+                rank[r] += (k0 < key[r] ? 1u : 0u) + (k1 < key[r] ? 1u : 0u) + (k2 < key[r] ? 1u : 0u) + (k3 < key[r] ? 1u : 0u);
+            }
+        }
+        lds_fence();
+        // a node's test partner: its sibling for a lo child, its parent's sibling for a hi child (none at the top)
+        auto partner_of = [&](uint32_t v) {
+            const uint32_t p = l_up(lds->lnk[v]);
+            uint32_t pa = kNil;
+            if (p != kNil) {
+                const uint32_t pw = lds->lnk[p];
+                if (l_hi(pw) != v) { pa = l_hi(pw); }
+                else if (l_up(pw) != kNil) {
+                    const uint32_t gw = lds->lnk[l_up(pw)];
+                    pa = l_lo(gw) == p ? l_hi(gw) : l_lo(gw);
+                }
+            }
+            return pa;
+        };
+#pragma unroll
+        for (int r = 0; r < kLeafRows; r++) {
+            const int v = BASE + r * kWave + lane;
+            if (v < kRoot) {
+                if (in[r]) {
+                    lds->rng[v] = ((uint32_t)POS0 + rank[r]) | (partner_of((uint32_t)v) << 20);
+                    lds->cnt[v] = (lds->cnt[v] & kCountMask) | (dep[r] << kDepthShift);
+                    if (CODES) { code[code_slot(v)] = cod[r]; }
+                } else {
+                    lds->rng[v] = kNoPos | (kNil << 20);
+                }
+            }
+        }
+        // internal nodes: first / last leaf by a walk down the lo / hi edge (a missing lo child: the hi one)
+#pragma unroll
+        for (int r = 0; r < kInnerRows; r++) {
+            const int v = kRoot + r * kWave + lane;
+            const bool on = v < next;
+            uint32_t f = on ? (uint32_t)v : (uint32_t)kRoot, l = f;
+            for (int it = 0; it <= kAuxDepth; it++) {
+                const bool mf = f >= (uint32_t)kRoot, ml = l >= (uint32_t)kRoot;
+                if (__ballot(mf | ml) == 0) { break; }
+                const uint32_t wf = lds->lnk[mf ? f : (uint32_t)kRoot], wl = lds->lnk[ml ? l : (uint32_t)kRoot];
+                if (mf) { f = l_lo(wf) != kNil ? l_lo(wf) : l_hi(wf); }
+                if (ml) { l = l_hi(wl) != kNil ? l_hi(wl) : l_lo(wl); }
+                if (f == kNil) { f = (uint32_t)kRoot - 1u; }           // (an empty tree: nothing to point at)
+                if (l == kNil) { l = (uint32_t)kRoot - 1u; }
+            }
+            if (v < BASE + NODES) {
+                lds->rng[v] = on ? (f | (l << 10) | (partner_of((uint32_t)v) << 20)) : (kNoPos | (kNil << 20));
+                if (on) { lds->cnt[v] &= kCountMask; }
+            }
+        }
+        lds_fence();
+        aux = 1;
+        return true;
     }
 
     // ---------------- passes over the leaves: one lane per leaf --------------------------------

@@ -163,10 +163,39 @@ def test_streams_equal_the_oracle(emu):
     assert back == [bytes(c) for c in cases]
     # the same streams through the decoder with 2 and 4 wavefronts per stream (read-ahead over 128 / 256
     # bit offsets per round, workgroup barriers between the waves: tests/emu runs the waves as they are)
-    for waves in (2, 4, 8):
-        back, derr = decode(D, want, [len(c) for c in cases], waves=waves)
-        assert derr.tolist() == [0] * len(cases), waves
-        assert back == [bytes(c) for c in cases], waves
+    # (every wave count in the default build; the lowered-threshold builds, whose deep-tree paths belong to the
+    # update side that wave 0 runs alone, with four waves on the streams that reach those paths)
+    for waves in ((2, 4, 8) if name == "default" else (4,)):
+        pick = list(range(len(cases))) if name == "default" else [0, 1, 8]
+        back, derr = decode(D, [want[k] for k in pick], [len(cases[k]) for k in pick], waves=waves)
+        assert derr.tolist() == [0] * len(pick), waves
+        assert back == [bytes(cases[k]) for k in pick], waves
+
+
+def slow_random_block(nbytes, block=38):
+    """uniform random bytes, generator seed 1, 256 KB blocks: in block 38 (and 47) the first fifty symbols -- each
+    seen once -- build a chain deeper than 26 levels down the literal tree's left edge, so the tree gives up its
+    leaf positions; it settles at depth 10 soon after and has to take them up again (sqz_tree.h: regain_aux)"""
+    bb = 262144
+    return np.random.default_rng(1).integers(0, 256, 64 * bb, dtype=np.uint8)[block * bb:block * bb + nbytes].tobytes()
+
+
+def test_a_tree_that_was_too_deep_takes_its_positions_up_again():
+    """give_up_aux at depth 26, regain_aux once the tree is shallow again: same streams as the oracle, and the
+    encoder is back on batches (the emulated kernel would need minutes for this input otherwise)"""
+    import time
+    E, D = _build("default", "emit"), _build("default", "decode")
+    data = slow_random_block(60000)
+    w = 1 << 15
+    t0 = time.time()
+    outs, err = emit(E, [O.tokens(data, w)], [len(data)])
+    took = time.time() - t0
+    want = O.encode(data, 15, header=False, window=w)
+    assert err.tolist() == [0] and outs == [want]
+    assert took < 20, f"the emulated emit kernel took {took:.0f} s: still one symbol at a time?"
+    for waves in (1, 4):
+        back, derr = decode(D, [want], [len(data)], waves=waves)
+        assert derr.tolist() == [0] and back == [data], waves
 
 
 def test_multi_wave_decoder_on_damaged_streams():
@@ -175,10 +204,10 @@ def test_multi_wave_decoder_on_damaged_streams():
     import random
     D = _build("default", "decode")
     rng = random.Random(21)
-    data = O.corpus("laozi.txt")[:6000]
+    data = O.corpus("laozi.txt")[:3000]
     good = O.encode(data, 12, header=False)
     streams = [good]
-    for _ in range(10):
+    for _ in range(6):
         bad = bytearray(good)
         bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
         streams.append(bytes(bad))
