@@ -289,7 +289,7 @@ int finder_default() {
 // SQZ_DECODE_WAVES=1|2|4|8 overrides.
 int decode_waves_for(uint32_t n_blocks) {
     static const int forced = [] { const char* e = getenv("SQZ_DECODE_WAVES"); return e != NULL ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 3 || forced == 4 || forced == 8) { return forced; }
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) { return forced; }
     int cus = ctx().cus;
     if (cus <= 0) { cus = 256; }
     if ((uint64_t)n_blocks <= (uint64_t)cus * 2) { return 8; }

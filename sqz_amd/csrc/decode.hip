@@ -1110,9 +1110,6 @@ void launch_entropy_decode(const uint8_t* in, const uint64_t* in_off, const uint
     } else if (waves >= 4) {
         hipLaunchKernelGGL(entropy_decode_mw_kernel<4>, dim3(n_blocks), dim3(kWave * 4), 0, stream,
                            in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
-    } else if (waves == 3) {        // (development: the multi-wave kernel's code with one wave)
-        hipLaunchKernelGGL(entropy_decode_mw_kernel<1>, dim3(n_blocks), dim3(kWave), 0, stream,
-                           in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
     } else if (waves >= 2) {
         hipLaunchKernelGGL(entropy_decode_mw_kernel<2>, dim3(n_blocks), dim3(kWave * 2), 0, stream,
                            in, in_off, out_off, tokens, tok_count, err, end_bit, n_blocks, start_bit);
