@@ -348,31 +348,32 @@ void index_match_kernel(const uint8_t* __restrict__ in,
         const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
         if (__ballot(valid && key == key0 && i + 16 <= n) == ~0ull) {
             // ---- the whole wave sits inside one run of equal keys (a frequent 3-byte string) ---
-            // Its lanes walk the same candidates, one rank apart.  Walk them ONCE: the candidate's
-            // position comes from a register page of sorted positions (v_readlane), its bytes from
-            // one broadcast load, and every lane compares them with its own first 16 bytes, held in
-            // registers -- no per-lane gathers.  Same order (nearest first), same strict >.
+            // Its lanes walk the same candidates, one rank apart.  Walk them ONCE: every lane compares the
+            // candidate with its own first 16 bytes, held in registers.  Same order (nearest first), same strict >.
             bool done = false, deferred = false;
             uint32_t resume = 0;
-            uint32_t page_base = r0, page = i;               // page = sorted positions of ranks [page_base, +64)
+            // page = sorted positions of ranks [page_base, +64) AND their first 16 bytes, one rank per lane: a
+            // candidate's position and bytes come out of these registers (v_readlane) -- one gather per 64
+            // candidates instead of a dependent load per candidate (each turn of this loop used to wait for it)
+            uint32_t page_base = r0, page = i, pb0 = own0, pb1 = own1, pb2 = own2, pb3 = own3;
             for (int64_t c = (int64_t)r0 + kWave - 2; c >= 0; c--) {
                 if (c < (int64_t)page_base) {
                     page_base -= (uint32_t)kWave;            // r0 is a multiple of 64: so is every page
                     page = S[page_base + (uint32_t)lane];
+                    load16(page, pb0, pb1, pb2, pb3);        // (zeros beyond the stream's end)
                 }
-                const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)page, (int)(c - (int64_t)page_base));
+                const int at = (int)(c - (int64_t)page_base);
+                const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)page, at);
                 const bool below = (int64_t)r > c;           // the candidate comes before my position
                 const uint32_t d = i - pc;
                 if (below && d > reach) { done = true; }     // everything further is farther
                 if (__ballot(!done) == 0) { break; }
-                const uint8_t* cp = src + pc;
-                // its key first: a rank in front of the run can be any position, also the last one
-                const uint32_t c0 = (pc + 4 <= n) ? load_u32_unaligned(cp)
-                    : ((uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16));
+                // its key first: a rank in front of the run can be any position
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)pb0, at);
                 if ((c0 & 0x00FFFFFFu) != key0) { break; }   // left the run: so have all earlier ranks
-                // inside the run positions grow with the rank: pc < lane 63's i, so pc + 16 <= n
-                const uint32_t c1 = load_u32_unaligned(cp + 4);
-                const uint32_t c2 = load_u32_unaligned(cp + 8), c3 = load_u32_unaligned(cp + 12);
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)pb1, at);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)pb2, at);
+                const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)pb3, at);
                 const uint32_t x0 = own0 ^ c0, x1 = own1 ^ c1, x2 = own2 ^ c2, x3 = own3 ^ c3;
                 uint32_t len = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3)
                              : x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
