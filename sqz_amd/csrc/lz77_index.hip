@@ -321,15 +321,42 @@ void index_match_kernel(const uint8_t* __restrict__ in,
         if (valid) { load16(i, own0, own1, own2, own3); }
         const uint32_t key = own0 & 0x00FFFFFFu;             // i <= n - 3: the key's bytes are the stream's
         uint32_t best = 0, dist = 0;
-        // one lane on its own: the candidates of ranks q_from-1, q_from-2, ... (nearest first)
+        // one lane on its own: the candidates of ranks q_from-1, q_from-2, ... (nearest first).
+        // Where the walk ends -- the first rank of the run, or the first candidate within reach, whichever is
+        // later -- is found FIRST (ranks are in position order inside a run, so "same key and within reach" is
+        // monotone: doubling steps, then bisection), and the lane's own byte at the length to beat is kept in
+        // a register: what is left per candidate is its position (neighbouring lanes read neighbouring ranks)
+        // and ONE scattered byte, where it used to be three scattered loads.  These walks are gather-bound
+        // (executables: a thousand candidates per position).
         auto walk = [&](uint32_t q_from) {
-            for (uint32_t q = q_from; q > 0 && best < cap; ) {
+            if (q_from == 0 || best >= cap) { return; }
+            auto inside = [&](uint32_t r) {                    // r < q_from <= own rank: S[r] < i when the key is the same
+                const uint32_t p = S[r];
+                if (p + 4 > n) { return false; }               // (another key's position may end the stream)
+                return (load_u32_unaligned(src + p) & 0x00FFFFFFu) == key && i - p <= reach;
+            };
+            uint32_t q_lo;                                     // candidates are ranks [q_lo, q_from)
+            {
+                uint32_t d = 4, bad = 0, good = q_from;       // ranks < bad... : `bad - 1` is outside or bad == 0
+                bool open = true;
+                while (open) {
+                    if (d >= q_from) { bad = 0; open = false; if (inside(0)) { good = 0; } else { bad = 1; } }
+                    else if (inside(q_from - d)) { good = q_from - d; d <<= 1; }
+                    else { bad = q_from - d + 1; open = false; }
+                }
+                // first inside rank is in [bad, good]
+                uint32_t lo = bad, hi = good;
+                while (lo < hi) {
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    if (inside(mid)) { hi = mid; } else { lo = mid + 1; }
+                }
+                q_lo = lo;
+            }
+            uint8_t own_next = best >= (uint32_t)kLenMin ? src[i + best] : (uint8_t)0;   // best < cap: i + best < n
+            for (uint32_t q = q_from; q > q_lo && best < cap; ) {
                 q--;
-                const uint32_t p = S[q];                       // p < i inside a run
-                if (i - p > reach) { break; }                  // everything further is farther
-                const uint32_t pk = load_u32_unaligned(src + p) & 0x00FFFFFFu;   // p < i: p+4 <= n
-                if (pk != key) { break; }                      // left the run
-                if (best >= (uint32_t)kLenMin && src[p + best] != src[i + best]) { continue; }
+                const uint32_t p = S[q];
+                if (best >= (uint32_t)kLenMin && src[p + best] != own_next) { continue; }
                 uint32_t k = 3;
                 while (k < cap) {
                     if (i + k + 4 <= n) {
@@ -342,7 +369,10 @@ void index_match_kernel(const uint8_t* __restrict__ in,
                     }
                 }
                 if (k > cap) { k = cap; }
-                if (k > best) { best = k; dist = i - p; }      // strictly longer: nearest among equals
+                if (k > best) {                                // strictly longer: nearest among equals
+                    best = k; dist = i - p;
+                    if (best < cap) { own_next = src[i + best]; }
+                }
             }
         };
         const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
