@@ -120,6 +120,20 @@ def test_window_sweep(sq, batch, window):
     assert outs[0] == O.encode(data, 15, header=False, window=window)
 
 
+def _record_table(rng, records):
+    """24-byte records with short zero fields, as an executable's symbol table has them: thousands of
+    positions share the zero trigram, their matches end after a few bytes and every in-window candidate has to
+    be looked at (index_match_kernel: the shared walk over whole pages, the lanes' own walks with their end
+    found by bisection, a window shorter than the run)."""
+    out = bytearray()
+    for k in range(records):
+        out += (k * 24).to_bytes(4, "little") + bytes(4)
+        out += bytes([rng.choice((0x12, 0x11, 0x10, 0x22)), 0, rng.choice((0, 0, 0x0E, 0x10)), 0])
+        out += rng.choice((0x401000, 0x402000, 0x0)).to_bytes(4, "little") + bytes(4)
+        out += rng.choice((0, 0, 8, 0x18, rng.randrange(1 << 10))).to_bytes(4, "little")
+    return bytes(out)
+
+
 @pytest.mark.parametrize("finder", ["index", "scan"])
 def test_tokens_vs_oracle(sq, batch, finder):
     """stage 1 alone, both finders (the bst.c:254-308 differential pattern: every
@@ -130,7 +144,8 @@ def test_tokens_vs_oracle(sq, batch, finder):
               O.corpus("confucius.txt")[:30000], b"", b"ab", b"abc", b"abcabc",
               bytes(rng.choice(b"ab") for _ in range(5000)), bytes(70000),
               O.corpus("x64.elf")[4096:4096 + 50000], O.corpus("arm64.elf")[:40000],
-              bytes(rng.choice(b"abc") for _ in range(300)) * 120]
+              bytes(rng.choice(b"abc") for _ in range(300)) * 120,
+              _record_table(rng, 2500)]
     sizes = [len(b) for b in blocks]
     off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device="cuda")
     d_in = torch.tensor(np.frombuffer(b"".join(blocks), np.uint8).copy(), device="cuda")
