@@ -13,6 +13,8 @@ SRC = os.path.join(ROOT, "tests", "harness", "sqz_harness.c")
 EXE = os.path.join(ROOT, "tests", "harness", "sqz_harness")
 SRC_B = os.path.join(ROOT, "tests", "harness", "sqz_boundary.c")
 EXE_B = os.path.join(ROOT, "tests", "harness", "sqz_boundary")
+SRC_RC = os.path.join(ROOT, "tests", "harness", "sqz_rc_harness.c")
+EXE_RC = os.path.join(ROOT, "tests", "harness", "sqz_rc_harness")
 
 
 @pytest.fixture(scope="module")
@@ -35,6 +37,17 @@ def boundary():
                            "-I" + os.path.join(ROOT, "include"), SRC_B, "-L" + libdir, "-lsqz_amd", "-lpthread",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE_B])
     return EXE_B
+
+
+@pytest.fixture(scope="module")
+def rc_harness():
+    from sqz_amd import build
+    build.build_native()
+    libdir = os.path.join(ROOT, "sqz_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror",
+                           "-I" + os.path.join(ROOT, "include"), SRC_RC, "-L" + libdir, "-lsqz_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE_RC])
+    return EXE_RC
 
 
 def test_boundary_names_compile_and_are_loud_without_gpu(boundary):
@@ -95,3 +108,45 @@ def test_harness_writes_the_reference_file_image(harness, tmp_path):
     with open(os.path.join(ROOT, "tests", "golden", "laozi.txt.w10.file"), "rb") as fh:
         assert kept.read_bytes() == fh.read()
     assert not os.path.exists(os.path.join(ROOT, "~compressed~.bin"))      # removed like test.c:170
+
+
+def test_rc_harness_is_c99_under_the_reference_names_and_loud_without_gpu(rc_harness):
+    """HEAD's harness (/root/reference/test.c) re-created over <sqz/sqz_rc.h> with the reference's own
+    spellings (SQZ_RC_REFERENCE_NAMES): compiles as C99; without a device rc.error = ENODEV"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([rc_harness], cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode == errno.ENODEV and "no gfx950 device" in p.stdout
+
+
+@pytest.mark.gpu
+def test_rc_harness_files_are_the_reference_streams_behind_its_header(rc_harness, tmp_path):
+    """every file of HEAD's main() that exists goes into "~compressed~.bin" through rc.write and comes back
+    through rc.read (test.c:57-182); the kept images are "squeeze4" + the size as a host-order uint64 +
+    the stream the compiled reference produces (golden_rc.json fingerprints), the printed lines are the
+    reference's (test.c:91-98)"""
+    import json
+    import struct
+    import oracle_lib as O
+    env = dict(os.environ, SQZ_HARNESS_KEEP=str(tmp_path))
+    corpus = os.path.join(ROOT, "tests", "corpus")
+    p = subprocess.run([rc_harness, corpus, "x64.elf", "mandrill.png"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1] == "ok", p.stdout + p.stderr
+    with open(os.path.join(ROOT, "tests", "golden", "golden_rc.json")) as fh:
+        gold = json.load(fh)
+    seen = 0
+    for c in gold["corpus"]:
+        kept = tmp_path / (c["file"] + ".rc.file")
+        if not os.path.exists(os.path.join(corpus, c["file"])):
+            continue
+        image = kept.read_bytes()
+        assert image[:8] == b"squeeze4" and struct.unpack("<Q", image[8:16])[0] == c["in_bytes"]
+        assert len(image) == 16 + c["out_bytes"] and O.fnv(image[16:]) == c["out_fnv"], c["file"]
+        pc = (16 + c["out_bytes"]) * 100.0 / c["in_bytes"]
+        line = '%7d -> %7d %6.2f%% of "%s"' % (c["in_bytes"], 16 + c["out_bytes"], pc, c["file"])
+        assert any(ln.endswith(line) and ln.startswith("bps: ") for ln in p.stdout.splitlines()), line
+        seen += 1
+    assert seen >= 3
+    assert not os.path.exists(tmp_path / "~compressed~.bin")              # removed like test.c:170
