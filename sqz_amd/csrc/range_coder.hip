@@ -1,10 +1,14 @@
 // sqz_amd/csrc/range_coder.hip -- the reference's HEAD ("R-era") codec on gfx950 (SURVEY.md section
 // 8f-1): an adaptive order-0 range coder over byte models.  File:line = /root/reference/src/sqz.c.
 //
-//   struct prob_model + Fenwick tree  :398-472   -> RcModel: 256 counts in LDS, 4 per lane; a
-//                                                   cumulative count is a prefix sum over the lanes
-//                                                   (wave_scan), a lookup by cumulative count one
-//                                                   __ballot -- no tree of partial sums to keep
+//   struct prob_model + Fenwick tree  :398-472   -> RcModel: 256 counts in REGISTERS, 4 per lane, and
+//                                                   beside them the sum of the lanes in front -- kept
+//                                                   up to date by one add per symbol (the lanes behind
+//                                                   the coded one), so a cumulative count is one
+//                                                   v_readlane and a lookup by cumulative count one
+//                                                   __ballot: no tree of partial sums, no prefix sum,
+//                                                   no LDS.  RcFlag: the two-symbol literal flag, two
+//                                                   wave-uniform counts
 //   rc_emit / rc_encode               :474-521   -> RcEncoder::put / encode
 //   rc_consume / rc_decode            :499-548   -> RcDecoder::consume / decode
 //   sqz_compress as HEAD runs it      :590-743   -> rc_encode_kernel: the finders are compiled out
@@ -14,8 +18,10 @@
 //
 // One wavefront per independent stream, running uniformly: the coder's state (low, range, code) is a
 // serial chain of 64-bit divisions per symbol, so the parallelism is across streams and, inside
-// one, across the 256 counts of a model.  Throughput is bounded by that chain (about 500
-// instructions per byte); what the batch buys is thousands of streams at once.
+// one, across the 256 counts of a model.  Throughput is bounded by that chain; what the batch buys is
+// thousands of streams at once.  The divisions are rc_div(): a double-precision estimate made low on
+// purpose, the exact remainder, a second estimate of what is left and at most two steps up -- about 60
+// instructions where the compiler's 64-bit division takes 200 (it was most of the 500 per byte).
 #include "sqz_device.h"
 #include "sqz_kernels.h"
 
@@ -25,59 +31,134 @@ constexpr int kRcEINVAL = 22, kRcERANGE = 34, kRcEILSEQ = 84, kRcENOBUFS = 105; 
 constexpr int kRcMinLen = 2, kRcMaxLen = 254;                                    // src/sqz.c:29-30
 
 struct RcLds {
-    uint32_t lit[256], size[256], byte[256], bits[256];      // struct prob_model x 4 (inc/sqz/sqz.h:73-76)
-    uint32_t dist[32][4];                                    // pm_dist[32], two symbols each (:77)
+    uint32_t dist[32][4];                                    // pm_dist[32], two symbols each (inc/sqz/sqz.h:77)
 };
 
-struct RcModel {
-    uint32_t* f;        // LDS: 256 counts (only the first n are ever non-zero)
-    uint32_t total;     // pm_total_freq (:451)
+// floor(a / d), exact, for wave-uniform operands (d == 0: all ones -- the callers test for that case
+// themselves, as the reference's EILSEQ / EINVAL checks do).  The quotient is estimated in double precision
+// with a reciprocal made LOW on purpose -- (1 - 2^-40) / d, good to 2^-41 -- so that the estimate cannot
+// exceed it: q1 = floor(a rdl), the remainder r = a - q1 d is then exact, non-negative and below
+// a 2^-39 + 2d < 2^26 d; the same estimate of r / d leaves less than 2d + 1: two conditional steps.  The
+// reciprocal belongs to the MODEL (its total changes by one per symbol): it is made when the total moves,
+// off the chain low/range -> next symbol that bounds a stream.
+__device__ __forceinline__ double rc_recip_low(uint64_t d) {
+    const double f = (double)d;
+#ifdef SQZ_WAVE_EMU
+    double x = 1.0 / f;
+#else
+    double x = __builtin_amdgcn_rcp(f);                      // v_rcp_f64, then two Newton steps (four fma):
+    x = __builtin_fma(__builtin_fma(-f, x, 1.0), x, x);      // whatever the first estimate's accuracy, far
+    x = __builtin_fma(__builtin_fma(-f, x, 1.0), x, x);      // inside the 2^-41 the margin allows
+#endif
+    return x * (1.0 - 0x1p-40);
+}
 
-    __device__ __forceinline__ void init(uint32_t* counts, uint32_t n, int lane) {     // pm_init :453-458
-        f = counts;
-        for (int k = lane; k < 256; k += kWave) { f[k] = (uint32_t)k < n ? 1u : 0u; }
+__device__ __forceinline__ uint64_t rc_div_lanes(uint64_t a, uint64_t d, double rdl) {
+    if (d == 0) { return ~0ull; }
+    uint64_t q = (uint64_t)((double)a * rdl);
+    uint64_t r = a - q * d;
+    const uint32_t q2 = (uint32_t)((double)r * rdl);         // < 2^26
+    q += q2;
+    r -= (uint64_t)q2 * d;
+    if (r >= d) { q++; r -= d; }
+    if (r >= d) { q++; }
+    return q;
+}
+__device__ __forceinline__ uint64_t rc_div_lanes(uint64_t a, uint32_t d, double rdl) {   // the usual case: a model's total
+    if (d == 0) { return ~0ull; }
+    uint64_t q = (uint64_t)((double)a * rdl);
+    uint64_t r = a - ((uint64_t)(uint32_t)q * d + (((uint64_t)((uint32_t)(q >> 32) * d)) << 32));   // mod 2^64
+    const uint32_t q2 = (uint32_t)((double)r * rdl);
+    q += q2;
+    r -= (uint64_t)q2 * d;
+    if (r >= d) { q++; r -= d; }
+    if (r >= d) { q++; }
+    return q;
+}
+// (the result is wave-uniform, and said to be: what follows -- low, range, the byte loop -- runs on the scalar unit)
+__device__ __forceinline__ uint64_t rc_div(uint64_t a, uint32_t d, double rdl) { return uni64(rc_div_lanes(a, d, rdl)); }
+__device__ __forceinline__ uint64_t rc_div(uint64_t a, uint64_t d) { return uni64(rc_div_lanes(a, d, rc_recip_low(d))); }
+
+struct RcModel {        // struct prob_model (inc/sqz/sqz.h:40-43) with up to 256 symbols
+    uint32_t c0, c1, c2, c3;   // this lane's counts: symbols 4 lane .. 4 lane + 3
+    uint32_t excl;             // the counts of the lanes in front of this one
+    uint32_t total;            // pm_total_freq (:451)
+    double rdl;                // rc_recip_low(total)
+
+    __device__ __forceinline__ void init(uint32_t n, int lane) {                       // pm_init :453-458
+        const uint32_t s0 = 4u * (uint32_t)lane;
+        c0 = s0 < n ? 1u : 0u; c1 = s0 + 1u < n ? 1u : 0u; c2 = s0 + 2u < n ? 1u : 0u; c3 = s0 + 3u < n ? 1u : 0u;
+        excl = s0 < n ? s0 : n;
         total = n;
+        rdl = rc_recip_low(n);
     }
     // start (counts below sym) and size of sym: pm_sum_of / freq (:447, :510)
     __device__ __forceinline__ void span_of(uint32_t sym, int lane, uint32_t& start, uint32_t& size) const {
-        const uint4 v = reinterpret_cast<const uint4*>(f)[lane];
-        const uint32_t s = v.x + v.y + v.z + v.w;
-        const uint32_t excl = wave_scan(s) - s;
+        (void)lane;
         const uint32_t k = sym & 3u;
-        const uint32_t below = excl + (k > 0 ? v.x : 0u) + (k > 1 ? v.y : 0u) + (k > 2 ? v.z : 0u);
-        const uint32_t mine = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        const uint32_t below = excl + (k > 0 ? c0 : 0u) + (k > 1 ? c1 : 0u) + (k > 2 ? c2 : 0u);
+        const uint32_t mine = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
         start = (uint32_t)__builtin_amdgcn_readlane((int)below, (int)(sym >> 2));
         size = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(sym >> 2));
     }
     // pm_index_of (:451, ft_index_of :432-445): the symbol whose run holds `sum`, with its span.  A sum
     // at or past the total (a damaged stream) is symbol 0 there (ft_index_of's -1, plus 1), not an error.
     __device__ __forceinline__ int find(uint64_t sum, int lane, uint32_t& start, uint32_t& size) const {
-        const uint4 v = reinterpret_cast<const uint4*>(f)[lane];
-        const uint32_t s = v.x + v.y + v.z + v.w;
-        const uint32_t excl = wave_scan(s) - s;
+        (void)lane;
+        const uint32_t s = c0 + c1 + c2 + c3;
         const uint32_t t = (uint32_t)sum;
-        const bool here = sum < (uint64_t)total && t >= excl && t < excl + s;
+        const bool here = sum < (uint64_t)total && t >= excl && t - excl < s;
         const uint64_t m = __ballot(here);
         if (m == 0) {
             start = 0;
-            size = (uint32_t)__builtin_amdgcn_readlane((int)v.x, 0);
+            size = (uint32_t)__builtin_amdgcn_readlane((int)c0, 0);
             return sum >= (uint64_t)total ? 0 : -1;
         }
         const int L = __builtin_ctzll(m);
-        const uint32_t c1 = excl + v.x, c2 = c1 + v.y, c3 = c2 + v.z;
-        const uint32_t k = t < c1 ? 0u : t < c2 ? 1u : t < c3 ? 2u : 3u;
-        const uint32_t below = k == 0 ? excl : k == 1 ? c1 : k == 2 ? c2 : c3;
-        const uint32_t mine = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        const uint32_t e1 = excl + c0, e2 = e1 + c1, e3 = e2 + c2;
+        const uint32_t k = t < e1 ? 0u : t < e2 ? 1u : t < e3 ? 2u : 3u;
+        const uint32_t below = k == 0 ? excl : k == 1 ? e1 : k == 2 ? e2 : e3;
+        const uint32_t mine = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
         start = (uint32_t)__builtin_amdgcn_readlane((int)below, L);
         size = (uint32_t)__builtin_amdgcn_readlane((int)mine, L);
         return 4 * L + (int)(uint32_t)__builtin_amdgcn_readlane((int)k, L);
     }
     __device__ __forceinline__ void update(uint32_t sym, int lane) {                    // pm_update :466-472
         // (the reference stops at a total of 2^56; a stream here is shorter than 2^31 symbols)
-        if (lane == 0) { f[sym] += 1u; }
+        const uint32_t at = sym >> 2, k = sym & 3u;
+        const uint32_t one = (uint32_t)lane == at ? 1u : 0u;
+        c0 += k == 0 ? one : 0u; c1 += k == 1 ? one : 0u; c2 += k == 2 ? one : 0u; c3 += k == 3 ? one : 0u;
+        excl += (uint32_t)lane > at ? 1u : 0u;
         total += 1u;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        asm volatile("" ::: "memory");
+        rdl = rc_recip_low(total);
+    }
+};
+
+struct RcFlag {         // the literal flag's model: two symbols (pm_literal, inc/sqz/sqz.h:73), wave-uniform
+    uint32_t f0, f1, total;
+    double rdl;
+    __device__ __forceinline__ void init(uint32_t n, int lane) {
+        (void)lane;
+        f0 = n > 0 ? 1u : 0u; f1 = n > 1 ? 1u : 0u; total = n;
+        rdl = rc_recip_low(n);
+    }
+    __device__ __forceinline__ void span_of(uint32_t sym, int lane, uint32_t& start, uint32_t& size) const {
+        (void)lane;
+        start = sym != 0 ? f0 : 0u;
+        size = sym != 0 ? f1 : f0;
+    }
+    __device__ __forceinline__ int find(uint64_t sum, int lane, uint32_t& start, uint32_t& size) const {
+        (void)lane;
+        const bool one = sum >= (uint64_t)f0 && sum < (uint64_t)total;   // (past the total: symbol 0, as above)
+        start = one ? f0 : 0u;
+        size = one ? f1 : f0;
+        return one ? 1 : 0;
+    }
+    __device__ __forceinline__ void update(uint32_t sym, int lane) {
+        (void)lane;
+        f0 += sym == 0 ? 1u : 0u; f1 += sym != 0 ? 1u : 0u;
+        total += 1u;
+        rdl = rc_recip_low(total);
     }
 };
 
@@ -105,11 +186,12 @@ struct RcEncoder {
     }
     __device__ __forceinline__ bool same_top() const { return (low >> 56) == ((low + range) >> 56); }   // :481-483
 
-    __device__ __forceinline__ void encode(RcModel& m, uint32_t sym, int lane) {         // rc_encode :506-521
+    template <class Model>
+    __device__ __forceinline__ void encode(Model& m, uint32_t sym, int lane) {           // rc_encode :506-521
         const uint64_t total = m.total;
         uint32_t start, size;
         m.span_of(sym, lane, start, size);
-        range /= total;
+        range = rc_div(range, m.total, m.rdl);
         low += (uint64_t)start * range;
         range *= (uint64_t)size;
         m.update(sym, lane);
@@ -126,13 +208,12 @@ __global__ __launch_bounds__(kWave)
 void rc_encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                       uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
                       uint64_t* __restrict__ out_bytes, int32_t* __restrict__ err_out, uint32_t n_blocks) {
-    __shared__ RcLds lds;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
-    RcModel lit, size, byte;
-    lit.init(lds.lit, 2, lane); size.init(lds.size, 256, lane); byte.init(lds.byte, 256, lane);   // sqz_init :550-565
-    __syncthreads();
+    RcFlag lit;
+    RcModel size, byte;
+    lit.init(2, lane); size.init(256, lane); byte.init(256, lane);                       // sqz_init :550-565
     const uint8_t* src = in + uni64(in_off[b]);
     const uint64_t bytes = uni64(in_off[b + 1]) - uni64(in_off[b]);
     RcEncoder rc;
@@ -182,7 +263,8 @@ struct RcDecoder {
     }
     __device__ __forceinline__ bool same_top() const { return (low >> 56) == ((low + range) >> 56); }
 
-    __device__ __forceinline__ uint32_t decode(RcModel& m, int lane) {                    // rc_decode :528-548
+    template <class Model>
+    __device__ __forceinline__ uint32_t decode(Model& m, int lane) {                      // rc_decode :528-548
         const uint64_t total = m.total;
         if (total < 1) { error = kRcEINVAL; return 0; }
         if (range < total) {
@@ -190,11 +272,12 @@ struct RcDecoder {
             consume(lane);
             range = ~0ull - low;
         }
-        const uint64_t sum = (code - low) / (range / total);
+        const uint64_t unit = rc_div(range, m.total, m.rdl);           // (0 when range < total: EILSEQ below)
+        const uint64_t sum = rc_div(code - low, unit);
         uint32_t start, size;
         const int sym = m.find(sum, lane, start, size);
         if (sym < 0 || size == 0 || range < total) { error = kRcEILSEQ; return 0; }
-        range /= total;
+        range = unit;
         low += (uint64_t)start * range;
         range *= (uint64_t)size;
         m.update((uint32_t)sym, lane);
@@ -212,8 +295,9 @@ void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) { return; }
-    RcModel lit, size, byte, bits;
-    lit.init(lds.lit, 2, lane); size.init(lds.size, 256, lane); byte.init(lds.byte, 256, lane); bits.init(lds.bits, 32, lane);
+    RcFlag lit;
+    RcModel size, byte, bits;
+    lit.init(2, lane); size.init(256, lane); byte.init(256, lane); bits.init(32, lane);
     if (lane < 32) { lds.dist[lane][0] = 1; lds.dist[lane][1] = 1; lds.dist[lane][2] = 0; lds.dist[lane][3] = 0; }
     __syncthreads();
     uint8_t* d = out + uni64(out_off[b]);
@@ -251,18 +335,17 @@ void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict
                 if (rc.error != 0) { break; }
                 uint32_t dd = 0;
                 for (int k = 0; k + 1 < (int)nb && rc.error == 0; k++) {                 // :817-819, one two-symbol model per bit
-                    RcModel m; m.f = lds.dist[k]; m.total = dist_total[k];
-                    // (a model is 256 counts wide for span/find: the dist models share the bits table's layout
-                    // only in their first four entries, so do the two-symbol arithmetic directly)
-                    const uint64_t total = m.total;
+                    // (the two-symbol arithmetic done directly on the pair's counts in LDS)
+                    const uint64_t total = dist_total[k];
                     if (rc.range < total) { rc.consume(lane); rc.consume(lane); rc.range = ~0ull - rc.low; }
-                    const uint64_t sum = (rc.code - rc.low) / (rc.range / total);
+                    const uint64_t unit = rc_div(rc.range, total);
+                    const uint64_t sum = rc_div(rc.code - rc.low, unit);
                     const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][0]);
                     const uint32_t f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][1]);
                     const uint32_t bit = (sum < f0 || sum >= total) ? 0u : 1u;      // (pm_index_of: past the total is symbol 0)
                     const uint32_t start = bit ? f0 : 0u, sz2 = bit ? f1 : f0;
                     if (rc.range < total) { rc.error = kRcEILSEQ; break; }
-                    rc.range /= total;
+                    rc.range = unit;
                     rc.low += (uint64_t)start * rc.range;
                     rc.range *= (uint64_t)sz2;
                     if (lane == 0) { lds.dist[k][bit] += 1u; }

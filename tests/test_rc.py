@@ -97,6 +97,33 @@ def test_oracle_against_reference_live():
             assert (er, back.raw[:got.value], cons.value) == (eo, bo, co)
 
 
+def test_the_kernels_division_is_exact():
+    """rc_div (range_coder.hip: a double-precision estimate made low, the exact remainder, a second estimate, two
+    steps) against 64-bit integer division: corners and two million random pairs of every magnitude"""
+    import test_emu as TE
+    E = TE._build("default", "rc")
+    E.emu_rc_div_mismatches.restype = C.c_uint64
+    rng = np.random.default_rng(5)
+    edge = np.array([0, 1, 2, 3, 255, 256, 2**31 - 1, 2**31, 2**32 - 1, 2**32, 2**32 + 1, 2**52, 2**53 - 1, 2**53,
+                     2**53 + 1, 2**56, 2**63 - 1, 2**63, 2**63 + 1, 2**64 - 2, 2**64 - 1], dtype=np.uint64)
+    a = [np.repeat(edge, len(edge)), ]
+    d = [np.tile(edge, len(edge)), ]
+    n = 1 << 20
+    for shift_a, shift_d in ((0, 0), (0, 32), (0, 45), (8, 40), (0, 56), (20, 20)):
+        a.append(rng.integers(0, 2**64, n, dtype=np.uint64) >> np.uint64(shift_a))
+        d.append((rng.integers(0, 2**64, n, dtype=np.uint64) >> np.uint64(shift_d)) | np.uint64(1))
+    # multiples of the divisor and their neighbours: the quotient changes exactly there
+    dd = (rng.integers(0, 2**64, n, dtype=np.uint64) >> np.uint64(40)) | np.uint64(1)
+    qq = rng.integers(0, 2**39, n, dtype=np.uint64)
+    for off in (0, 1, -1):
+        a.append((dd * qq + np.uint64(off & (2**64 - 1))).astype(np.uint64))
+        d.append(dd)
+    a, d = np.ascontiguousarray(np.concatenate(a)), np.ascontiguousarray(np.concatenate(d))
+    bad = C.c_uint64(0)
+    wrong = E.emu_rc_div_mismatches(a.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_uint64(len(a)), C.byref(bad))
+    assert wrong == 0, (wrong, int(a[bad.value]), int(d[bad.value]))
+
+
 def test_kernels_on_the_wave_emulator():
     import test_emu as TE
     TE.VARIANTS.setdefault("default", [])
