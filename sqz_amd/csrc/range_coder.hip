@@ -101,22 +101,25 @@ struct RcModel {        // struct prob_model (inc/sqz/sqz.h:40-43) with up to 25
         start = (uint32_t)__builtin_amdgcn_readlane((int)below, (int)(sym >> 2));
         size = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(sym >> 2));
     }
-    // pm_index_of (:451, ft_index_of :432-445): the symbol whose run holds `sum`, with its span.  A sum
-    // at or past the total (a damaged stream) is symbol 0 there (ft_index_of's -1, plus 1), not an error.
-    __device__ __forceinline__ int find(uint64_t sum, int lane, uint32_t& start, uint32_t& size) const {
+    // pm_index_of (:451, ft_index_of :432-445) of sum = floor(x / unit): the symbol whose run holds it, with its
+    // span.  The quotient itself is never formed: start <= floor(x / unit) < start + size is the same as
+    // start unit <= x < (start + size) unit (no product exceeds total unit <= range), and every lane tests
+    // its own run at once -- a 64-bit division with a divisor that is only known on the chain (two per
+    // symbol was most of the decoder) becomes five multiplications per lane.  A sum at or past the total
+    // (a damaged stream) is symbol 0 there (ft_index_of's -1, plus 1), not an error.
+    __device__ __forceinline__ int find(uint64_t x, uint64_t unit, int lane, uint32_t& start, uint32_t& size) const {
         (void)lane;
-        const uint32_t s = c0 + c1 + c2 + c3;
-        const uint32_t t = (uint32_t)sum;
-        const bool here = sum < (uint64_t)total && t >= excl && t - excl < s;
+        const uint32_t e1 = excl + c0, e2 = e1 + c1, e3 = e2 + c2, e4 = e3 + c3;
+        const uint64_t p0 = (uint64_t)excl * unit, p4 = (uint64_t)e4 * unit;
+        const bool here = x >= p0 && x < p4;                       // (the last run ends at total unit: sum < total)
         const uint64_t m = __ballot(here);
         if (m == 0) {
             start = 0;
             size = (uint32_t)__builtin_amdgcn_readlane((int)c0, 0);
-            return sum >= (uint64_t)total ? 0 : -1;
+            return x >= (uint64_t)total * unit ? 0 : -1;
         }
         const int L = __builtin_ctzll(m);
-        const uint32_t e1 = excl + c0, e2 = e1 + c1, e3 = e2 + c2;
-        const uint32_t k = t < e1 ? 0u : t < e2 ? 1u : t < e3 ? 2u : 3u;
+        const uint32_t k = x < (uint64_t)e1 * unit ? 0u : x < (uint64_t)e2 * unit ? 1u : x < (uint64_t)e3 * unit ? 2u : 3u;
         const uint32_t below = k == 0 ? excl : k == 1 ? e1 : k == 2 ? e2 : e3;
         const uint32_t mine = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
         start = (uint32_t)__builtin_amdgcn_readlane((int)below, L);
@@ -147,9 +150,9 @@ struct RcFlag {         // the literal flag's model: two symbols (pm_literal, in
         start = sym != 0 ? f0 : 0u;
         size = sym != 0 ? f1 : f0;
     }
-    __device__ __forceinline__ int find(uint64_t sum, int lane, uint32_t& start, uint32_t& size) const {
+    __device__ __forceinline__ int find(uint64_t x, uint64_t unit, int lane, uint32_t& start, uint32_t& size) const {
         (void)lane;
-        const bool one = sum >= (uint64_t)f0 && sum < (uint64_t)total;   // (past the total: symbol 0, as above)
+        const bool one = x >= (uint64_t)f0 * unit && x < (uint64_t)total * unit;   // (past the total: symbol 0, as above)
         start = one ? f0 : 0u;
         size = one ? f1 : f0;
         return one ? 1 : 0;
@@ -273,9 +276,8 @@ struct RcDecoder {
             range = ~0ull - low;
         }
         const uint64_t unit = rc_div(range, m.total, m.rdl);           // (0 when range < total: EILSEQ below)
-        const uint64_t sum = rc_div(code - low, unit);
         uint32_t start, size;
-        const int sym = m.find(sum, lane, start, size);
+        const int sym = m.find(code - low, unit, lane, start, size);   // (code - low) / unit, without the division
         if (sym < 0 || size == 0 || range < total) { error = kRcEILSEQ; return 0; }
         range = unit;
         low += (uint64_t)start * range;
@@ -339,10 +341,10 @@ void rc_decode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict
                     const uint64_t total = dist_total[k];
                     if (rc.range < total) { rc.consume(lane); rc.consume(lane); rc.range = ~0ull - rc.low; }
                     const uint64_t unit = rc_div(rc.range, total);
-                    const uint64_t sum = rc_div(rc.code - rc.low, unit);
+                    const uint64_t x = rc.code - rc.low;
                     const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][0]);
                     const uint32_t f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.dist[k][1]);
-                    const uint32_t bit = (sum < f0 || sum >= total) ? 0u : 1u;      // (pm_index_of: past the total is symbol 0)
+                    const uint32_t bit = (x < (uint64_t)f0 * unit || x >= total * unit) ? 0u : 1u;   // (pm_index_of: past the total is symbol 0)
                     const uint32_t start = bit ? f0 : 0u, sz2 = bit ? f1 : f0;
                     if (rc.range < total) { rc.error = kRcEILSEQ; break; }
                     rc.range = unit;
