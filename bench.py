@@ -219,6 +219,7 @@ def run_rc(args, torch, dist, batch, shard, info, dev, comm_dev, rank, world, lo
     dec_ms = dtim["rc_decode_kernel"][0] / max(dtim["rc_decode_kernel"][1], 1)
     algo = n * bb + comp_bytes                   # every input byte read once, every output byte written once
     achieved = algo / (enc_ms * 1e-3) / 1e9
+    rc_traffic, rc_traffic_note = measured_traffic("rc_encode_kernel")   # (tools/r03_final.sh PART=rc adds the R-era kernels)
     line = {
         "metric": "R-era range coder (SURVEY.md 8f-1): encode MB/s + decode MB/s, batched blocks",
         "value": round(in_total / enc_s * args.steps / 1e6, 3), "unit": "MB/s",
@@ -237,7 +238,7 @@ def run_rc(args, torch, dist, batch, shard, info, dev, comm_dev, rank, world, lo
         "kernels_ms": {"rc_encode_kernel": round(enc_ms, 3), "rc_decode_kernel": round(dec_ms, 3)},
         "roofline": {"bound": "hbm", "kernel": "rc_encode_kernel", "achieved": round(achieved, 4),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 7),
-                     "traffic": None, "traffic_note": "no PMC pass for the R-era kernels",
+                     "traffic": rc_traffic, "traffic_note": rc_traffic_note,
                      "algorithmic_bytes_per_launch": algo,
                      "decode_frac_of_hbm_roof": round(algo / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 7)},
     }

@@ -18,6 +18,13 @@ with open(os.path.join(dst, "traffic.json")) as fh:
     t = json.load(fh)
 with open(os.path.join(src, "traffic_current.json")) as fh:
     t["current"] = json.load(fh)
+# the R-era kernels' own passes (tools/r03_final.sh PART=rc), same sources: merged into the same slot
+rc = os.path.join(ROOT, "gpurun_out", f"{tag}_rc_pmc_hbm.json")
+if os.path.exists(rc):
+    with open(rc) as fh:
+        t["current"]["kernels"].update(json.load(fh)["kernels"])
+    shutil.copyfile(rc, os.path.join(dst, f"{tag}_rc_pmc_hbm.json"))
+    shutil.copyfile(os.path.join(ROOT, "gpurun_out", f"{tag}_rc_kernel_stats.csv"), os.path.join(dst, f"{tag}_rc_kernel_stats.csv"))
 t.setdefault("history", {})[tag] = t["current"]
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
     json.dump(t, fh, indent=1)
