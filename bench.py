@@ -468,7 +468,7 @@ def main():
                     "rank0_ms": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
                     "gathered_bytes": int(root_off[-1]),
                     "path": "rank 0 -> scatter (equal slabs) -> encode -> pack -> gather sizes + "
-                            f"dense streams (point-to-point per peer) -> rank 0, backend {backend}",
+                            f"dense streams (padded to the longest rank's) -> rank 0, backend {backend}",
                     # what stands behind this leg until a multi-GPU run has been recorded
                     "evidence": "shard.py over RCCL: world-1 nccl test on one MI355X (tests/test_shard_nccl.py); "
                                 "world-2: gloo rehearsal only (tests/test_shard_gpu.py, tools/rehearse_n2.sh)"}

@@ -4,7 +4,8 @@ One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo
 in the CPU tests).  Blocks are self-contained streams, so the data path needs no
 collective: rank r owns the contiguous block range block_range(n, r, world).
 The optional scatter / gather pair moves a root-resident batch out to the ranks and
-the compressed slabs back (point-to-point per peer link, no ring).
+the compressed streams back (ncclScatter / ncclGather shapes: one transfer per peer link,
+no ring).
 
 The codec is passed in as a callable, this module never touches kernels itself."""
 import torch
@@ -80,11 +81,15 @@ def dense_offsets(sizes):
 
 def gather_dense(local_dense, local_sizes, n_blocks: int, device, group=None, dst=0):
     """Variable-sized compressed streams back to `dst` in block order, without shipping the
-    worst-case slabs: every rank has packed its streams back to back (sqz_hip_pack_blocks),
-    `dst` first gathers the sizes (ncclGather shape, rccl.h:745), then receives every rank's
-    dense bytes with one point-to-point transfer per peer straight into its place in the
-    root image (grouped ncclSend / ncclRecv, rccl.h:700,722: one stream per xGMI link, no
-    ring).  local_dense: uint8[>= dense_offsets(local_sizes)[-1]].
+    worst-case slabs: every rank has packed its streams back to back (sqz_hip_pack_blocks);
+    the ranks gather the sizes (ncclGather shape, rccl.h:745), agree on the largest dense
+    image of any rank (all_reduce MAX) and gather the dense images padded to that length --
+    independent streams of one batch compress to within a few percent of one another, so the
+    padding is small -- and `dst` moves every rank's part to its place in the root image.
+    Collectives only, the same call on every rank: a lone `send` on the peers against grouped
+    receives on the root would meet different communicators under the nccl backend (single
+    point-to-point calls use a two-rank communicator, grouped ones the group's own).
+    local_dense: uint8[>= dense_offsets(local_sizes)[-1]].
 
     Returns (dense uint8[total], sizes int64[n_blocks], offsets int64[n_blocks+1]) on dst and
     (None, None, None) elsewhere; the triple is what sqz_hip_decode_blocks takes."""
@@ -95,27 +100,26 @@ def gather_dense(local_dense, local_sizes, n_blocks: int, device, group=None, ds
     pad_sizes[:local_sizes.numel()] = local_sizes.to(device)
     sizes_list = [torch.empty_like(pad_sizes) for _ in range(world)] if rank == dst else None
     dist.gather(pad_sizes, sizes_list, dst=dst, group=group)
+    total = int(dense_offsets(local_sizes)[-1])
+    longest = int(max_over_ranks(float(total), device, group))       # (exact: far below 2^53)
+    parts = None
+    if longest > 0:                                                  # (every rank sees the same `longest`)
+        mine = torch.empty(longest, dtype=torch.uint8, device=device)
+        mine[:total] = local_dense[:total].to(device)
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, parts, dst=dst, group=group)
     if rank != dst:
-        total = int(dense_offsets(local_sizes)[-1])
-        if total > 0:
-            dist.send(local_dense[:total].to(device), dst=dst, group=group)
         return None, None, None
     sizes = torch.cat([sizes_list[r][:block_range(n_blocks, r, world)[1] - block_range(n_blocks, r, world)[0]]
                        for r in range(world)])
     off = dense_offsets(sizes)
     host_off = off.cpu()
     dense = torch.empty(int(host_off[-1]), dtype=torch.uint8, device=device)
-    ops = []
     for r in range(world):
         lo, hi = block_range(n_blocks, r, world)
         a, b = int(host_off[lo]), int(host_off[hi])
-        if r == dst:
-            dense[a:b] = local_dense[:b - a].to(device)
-        elif b > a:
-            ops.append(dist.P2POp(dist.irecv, dense[a:b], r, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        if b > a:
+            dense[a:b] = parts[r][:b - a]
     return dense, sizes, off
 
 

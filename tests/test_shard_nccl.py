@@ -1,6 +1,6 @@
 """GPU, backend `nccl` (= RCCL on ROCm), world_size 1 on the one device of the box: every shard.py call of
 BASELINE.json configs[3]'s transfer leg on DEVICE uint8 tensors -- scatter_blocks, gather_dense (the
-sizes gather, the rank == dst copy and the P2POp branch logic with no peers), gather_slabs,
+sizes gather, the agreement on the longest dense image, the padded gather and the root's placement), gather_slabs,
 max / min / sum_over_ranks -- around a HIP encode, the gathered streams compared with the oracle.
 What two ranks add (real peer transfers) needs two GPUs; what this pins is that the calls, dtypes and
 device tensors bench.py hands to RCCL are accepted by it (rccl.h:700-767).
