@@ -88,6 +88,12 @@ def kernel_build_id():
     return h.hexdigest()[:16]
 
 
+# Kernels whose reads are ONE coalesced pass over a stream of known length, and whose raw FETCH_SIZE is half of that
+# length on gfx950 (emit: 1.55 GB counted for 3.07 GB of token words; entropy decode: 0.48 GB for 0.92 GB of
+# streams; the R-era kernels carry the doubling in their own file, tools/r03_final.sh): their FETCH_SIZE is doubled.
+HALVED_FETCH = ("huffman_emit_kernel", "entropy_decode_kernel")
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the last committed PMC run (profiles/traffic.json,
     written by tools/profile_round.sh) -- but only if it was measured on THESE kernels."""
@@ -105,6 +111,12 @@ def measured_traffic(kernel):
     k = ks.get(kernel) or next((v for n, v in ks.items() if n.split("<")[0].split()[-1] == kernel), None)
     if not k:
         return None, "kernel not in profiles/traffic.json"
+    if kernel in HALVED_FETCH and "hbm_bytes_per_launch_if_fetch_doubled" in k:
+        return int(k["hbm_bytes_per_launch_if_fetch_doubled"]), (
+            "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only), KiB -> bytes, "
+            "per launch; FETCH_SIZE DOUBLED: this kernel's reads are one coalesced pass over a stream of known length "
+            "and the raw counter is half of it (MI355X_MICROARCH.md, HBM section: gfx950 reports half the bytes of "
+            "coalesced streaming reads); WRITE_SIZE exact")
     return int(k["hbm_bytes_per_launch"]), cur.get("method")
 
 

@@ -37,9 +37,10 @@ out = {k: {"fetch_kib_raw": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"
 json.dump(out, open(O + "/pmc_hbm.json", "w"), indent=1)
 # MI355X_MICROARCH.md (HBM / rocprofv3): counters are KiB; on gfx950 FETCH_SIZE reports half the
 # bytes of a wide (16 B per lane) coalesced streaming read and is doubled for those; WRITE_SIZE is
-# exact.  Which kernels stream 16 B per lane is a property of the code: none of the current ones do
-# for the bulk of their reads (dword / byte gathers, 4 B per lane), so FETCH_SIZE is taken as is
-# and the doubled figure is kept beside it as the upper bound.
+# exact.  Round 3 found the halving on 4-byte and 1-byte coalesced loads too (kernels whose read volume is
+# known to the byte: emit, entropy decode, the R-era pair), so this file keeps BOTH figures per kernel and
+# bench.py (HALVED_FETCH) picks the doubled one for the kernels that read one coalesced stream; gathers
+# (match, expand) stay raw.
 cur = {"kernel_build_id": bench.kernel_build_id(),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only) of "
                  "`python bench.py --steps 1 --warmup 0 --cpu-blocks 0 --no-verify`; KiB -> bytes; per launch; "

@@ -36,9 +36,15 @@ out = {}
 for k, v in acc.items():
     l = max(len(n[k].get("FETCH_SIZE", ())), 1)
     f, w = (v.get("FETCH_SIZE") or 0.0) * 1024 / l, (v.get("WRITE_SIZE") or 0.0) * 1024 / l
-    out[k] = {"launches": l, "fetch_bytes": int(f), "write_bytes": int(w), "hbm_bytes_per_launch": int(f + w)}
+    # these kernels read their input once, 64 consecutive bytes per wave and load: FETCH_SIZE comes out at HALF of
+    # what they must read (encode: 0.54 GB for the 1.07 GB batch; decode: 0.42 GB for 0.84 GB of streams) while
+    # WRITE_SIZE equals the bytes written to the byte -- the gfx950 halving of MI355X_MICROARCH.md (HBM section)
+    # applies to them, so FETCH_SIZE is doubled here
+    out[k] = {"launches": l, "fetch_bytes_raw": int(f), "fetch_bytes": int(2 * f), "write_bytes": int(w),
+              "hbm_bytes_per_launch": int(2 * f + w)}
 json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only; KiB -> bytes; "
-                     "per launch; FETCH_SIZE as read (byte / dword loads, no 16-B-per-lane streaming)", "kernels": out},
+                     "per launch; FETCH_SIZE doubled (gfx950 reports half the bytes of these coalesced streaming reads: "
+                     "the raw figure is half of what the kernel must read, WRITE_SIZE is exact)", "kernels": out},
           open(f"gpurun_out/{tag}_rc_pmc_hbm.json", "w"), indent=1)
 print(json.dumps(out))
 PY
