@@ -29,7 +29,7 @@ def test_block_range_partition():
     assert shard.block_range(4096, 3, 8) == (1536, 2048)      # 512 per GPU
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N_BLOCKS=N_BLOCKS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,19 +75,20 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_scatter_encode_gather_world2():
+@pytest.mark.parametrize("world,n_blocks", [(2, N_BLOCKS), (3, 2)])      # (3, 2): the root itself owns no block
+def test_scatter_encode_gather_world2(world, n_blocks):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_blocks)) for r in range(world)]
     for p in procs:
         p.start()
     got, total = q.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    want = [O.encode(O.zipf_block(b, BLOCK), WB, header=False) for b in range(N_BLOCKS)]
+    want = [O.encode(O.zipf_block(b, BLOCK), WB, header=False) for b in range(n_blocks)]
     assert got == want                       # gathered results concatenate in block order
     assert total == float(sum(len(w) for w in want))
